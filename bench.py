@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- the ray-march hot path on BASELINE.json's headline workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one frame: one launch of the ray-march kernel over this rank's image-row
+shard, plus (N>1) the RCCL all_gather + de-interleave that puts the whole frame on every
+rank.  Workload (config.workload): synthetic 1024^3 uint16 volume generated in HBM,
+1920x1080 RGBA32F target, reference default camera, NEAREST sampling (the reference's
+effective filter), window [0,4095], alpha_scale 0.004 ("deep": no early ray
+termination, every ray traverses the whole box).  The frame is fixed while N grows
+(strong scaling): rank k renders cyclic 16-row stripes k, k+N, ...
+
+Prints ONE JSON line on rank 0.  `value` = samples actually fetched by the whole job per
+second (Msamples/s), inputs resident in HBM; `mpixels_per_s` is the companion number of
+BASELINE.json's metric.  `roofline` uses the algorithmic bytes of SURVEY 8(d):
+S*b + W*H*16 per launch over the kernel's average launch duration measured with HIP
+events on the launch stream.  `cpu_baseline` is the scalar oracle (oracle/vr_oracle.c,
+"port") timed on this box's host cores on a bounded row sample of the same frame.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--volume", type=int, default=1024, help="synthetic volume edge (voxels)")
+    ap.add_argument("--bytes", type=int, default=2, choices=(1, 2))
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--alpha", type=float, default=0.004)
+    ap.add_argument("--filter", choices=("nearest", "trilinear"), default="nearest")
+    ap.add_argument("--layout", choices=("linear", "bricked"), default=os.environ.get("VR_BENCH_LAYOUT", "linear"))
+    ap.add_argument("--partition", choices=("stripes", "contiguous"), default="stripes")
+    ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-stride", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
+    ap.add_argument("--extras", action="store_true", help="also time the secondary regimes (shallow / trilinear)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    vra = importlib.import_module("volume-renderer_amd")
+    from importlib import import_module
+
+    sharding = import_module("volume-renderer_amd.sharding")
+    R = vra.renderer
+
+    W, H, N, b = args.width, args.height, args.volume, args.bytes
+    vmax = 4095 if b == 2 else 255
+    r = vra.RendererCore(local_rank)
+    r.setup((W, H))
+    r.loadShader("VolumeRenderer.cs")
+    r.setQuirks(0)   # explicit window below is what the kernel sees (no +1000, no truncated grid)
+    r.setLayout(R.LAYOUT_BRICKED if args.layout == "bricked" else R.LAYOUT_LINEAR)
+    r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
+    r.setWindow(0, vmax)
+    r.setAlpha(args.alpha)
+    r.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
+    if args.pose == "offaxis":
+        r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)   # zenith 60 deg, azimuth 45 deg
+
+    plan = sharding.plan_rows(H, world, rank, args.partition, args.stripe_rows)
+    sharding.apply_plan(r, plan)
+    stream = torch.cuda.current_stream(dev)
+    r.setStream(stream.cuda_stream)
+    local = torch.zeros((plan.local_rows, W, 4), dtype=torch.float32, device=dev)
+    r.setFramebufferExternal(local.data_ptr())
+    r.setFramebufferCompact(True)
+    gathered = torch.empty((world * plan.local_rows, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    index = torch.as_tensor(sharding.gather_index(plan), device=dev) if world > 1 and plan.mode == "stripes" else None
+
+    # ---- untimed: exact sample count of this rank's shard (instrumented kernel)
+    r.setFramebufferExternal(0)
+    r.setFramebufferCompact(False)
+    my_samples = r.countSamples()
+    r.setFramebufferExternal(local.data_ptr())
+    r.setFramebufferCompact(True)
+    total_samples = my_samples
+    if world > 1:
+        t = torch.tensor([my_samples], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        total_samples = int(t.item())
+
+    def step():
+        r.renderAsync()
+        return sharding.gather_frame(local, plan, out=gathered, index=index)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    frame = None
+    for _ in range(args.warmup):
+        frame = step()
+    barrier()
+    # kernel-only duration: HIP events on the launch stream around each launch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        r.renderAsync()
+        ev[i][1].record(stream)
+        frame = sharding.gather_frame(local, plan, out=gathered, index=index)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = sum(a.elapsed_time(c) for a, c in ev) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max = float(t[0].item()), float(t[1].item())
+    else:
+        kernel_ms_max = kernel_ms
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    result = None
+    if rank == 0:
+        value = total_samples / (ms_per_step * 1e-3) / 1e6
+        mpix = W * H / (ms_per_step * 1e-3) / 1e6
+        alg_bytes = my_samples * b + plan_pixels(plan, W) * 16      # this rank's launch
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Msamples/sec (+ Mpixels/sec), 1024^3 uint16 @ 1920x1080",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "mpixels_per_s": round(mpix, 1),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "kernel_ms": round(kernel_ms_max, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 compositing over u%d voxels" % (8 * b),
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic noise-ball {N}^3 uint{8 * b} (generated in HBM, seed 0x9E3779B9), "
+                            f"{W}x{H} RGBA32F, reference default camera" + (" (off-axis pose)" if args.pose != "default" else "")
+                            + f", {args.filter.upper()} filter, window [0,{vmax}], alpha_scale {args.alpha}, "
+                            f"iterative accumulation, {args.layout} layout",
+                "samples_per_frame": total_samples,
+                "partition": "single GPU" if world == 1 else f"{args.partition} rows x{world}"
+                             + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
+                             + " + RCCL all_gather",
+                "kernel": r.last_kernel_name,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": load_traffic(args, world),
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
+        if world == 1 and args.extras:
+            result["extras"] = extras(args, r, local, stream)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def plan_pixels(plan, W):
+    import numpy as np
+
+    return int((plan.global_rows() >= 0).sum()) * W
+
+
+def load_traffic(args, world):
+    """HBM bytes per launch from the committed PMC profile of this same command
+    (profiles/traffic.json, written by tools/pmc_traffic.py), or null."""
+    p = ROOT / "profiles" / "traffic.json"
+    if world != 1 or not p.exists():
+        return None
+    try:
+        d = json.loads(p.read_text())
+        key = f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
+        return d.get(key)
+    except Exception:
+        return None
+
+
+def cpu_baseline(args, r, frame, gpu_msamples):
+    """Scalar oracle ("port") on host cores: a bounded row sample of the same frame,
+    single thread; also checks those rows against the GPU frame."""
+    import numpy as np
+    import oracle   # test infrastructure: timed as the CPU baseline, never on the product path
+
+    W, H, b = args.width, args.height, args.bytes
+    vmax = 4095 if b == 2 else 255
+    vol = r.readVolume()
+    cam = r.getCameraBlock()
+    gpu = frame.cpu().numpy()
+
+    def run(rows, threads):
+        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=0, max_val=vmax,
+                                filter=1 if args.filter == "trilinear" else 0, threads=threads)
+        out = np.zeros((H, W, 4), dtype=np.float32)
+        samples, secs = 0, 0.0
+        for y in rows:
+            p.row_begin, p.row_end = int(y), int(y) + 1
+            t0 = time.perf_counter()
+            _, s = oracle.render(vol, p, out=out)
+            secs += time.perf_counter() - t0
+            samples += s
+        return out, samples, secs
+
+    # calibrate on 4 rows through the middle, then pick a stride for ~15 s
+    probe_rows = [H // 2 - 60, H // 2 - 20, H // 2 + 20, H // 2 + 60]
+    _, ps, pt = run(probe_rows, 1)
+    rate = ps / max(pt, 1e-9)
+    stride = args.cpu_row_stride
+    if stride <= 0:
+        est_full = 4.8e8 * (args.volume / 1024.0) * (W * H) / (1920 * 1080) / max(rate, 1.0)
+        stride = max(1, int(np.ceil(est_full / 15.0)))
+    rows = list(range(stride // 2, H, stride))
+    out, samples, secs = run(rows, 1)
+    diff = float(np.max(np.abs(out[rows] - gpu[rows])))
+    bitexact = bool(np.array_equal(out[rows].view(np.uint32), gpu[rows].view(np.uint32)))
+    return {
+        "value": round(samples / secs / 1e6, 2),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"every {stride}th image row ({len(rows)} of {H} rows, {samples} samples, {secs:.1f} s) of the same frame",
+        "host_cores_available": os.cpu_count(),
+        "parity_max_abs_diff_on_sample": diff,
+        "parity_bit_exact_on_sample": bitexact,
+        "gpu_over_cpu": round(gpu_msamples / (samples / secs / 1e6), 1),
+    }
+
+
+def extras(args, r, local, stream):
+    """secondary regimes, timed the same way (kernel only, single GPU)"""
+    import torch
+
+    vra = importlib.import_module("volume-renderer_amd")
+    R = vra.renderer
+    out = {}
+
+    def timed(name, steps=10):
+        r.setFramebufferExternal(0); r.setFramebufferCompact(False)
+        s = r.countSamples()
+        r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
+        for _ in range(3):
+            r.renderAsync()
+        torch.cuda.synchronize()
+        a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(steps):
+            r.renderAsync()
+        c.record(stream)
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(c) / steps
+        out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
+                     "mpixels_per_s": round(args.width * args.height / ms / 1e3, 1), "kernel": r.last_kernel_name}
+
+    r.setAlpha(1.0)
+    timed("shallow_alpha1_ert")
+    r.setAlpha(args.alpha)
+    r.setFilter(R.FILTER_TRILINEAR)
+    timed("trilinear_deep", steps=5)
+    r.setFilter(R.FILTER_NEAREST)
+    r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)
+    timed("offaxis_deep")
+    r.resetCamera()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * vr_core.h -- C ABI of libvr_core.so, the MI355X (gfx950) replacement for the GPU
+ * ray-march path of gallickgunner/Volume-Renderer.
+ *
+ * The reference has no FFI: the boundary is the C++ surface of `RendererCore`
+ * (include/RendererCore.h:9-44) as used by its only caller `RendererGUI`
+ * (a friend class, src/RendererGUI.cpp).  Each entry point below names the
+ * reference member / call site it replaces.  All calls are single-threaded per
+ * handle, like the reference (everything runs on the GL thread).
+ *
+ * Conventions: functions returning `int` return 0 (VR_OK) on success and a
+ * VR_E_* code otherwise; the text is available from vr_last_error().
+ * Recoverable errors that the reference reports through its `title`/`msg`
+ * strings (src/RendererGUI.cpp:90-95) are ALSO queued for vr_take_message().
+ * Nothing here falls back to a CPU renderer: without a HIP device vr_render()
+ * fails with VR_E_NO_DEVICE.
+ */
+#ifndef VR_CORE_H
+#define VR_CORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vr_renderer *vr_handle;
+
+enum {
+    VR_OK = 0,
+    VR_E_INVALID = 1,     /* bad argument / call order                        */
+    VR_E_NO_DEVICE = 2,   /* no HIP device (or host-only handle) for a GPU op */
+    VR_E_HIP = 3,         /* HIP runtime error                                */
+    VR_E_IO = 4,          /* file open / parse error                          */
+    VR_E_NOMEM = 5
+};
+
+enum { VR_FILTER_NEAREST = 0, VR_FILTER_TRILINEAR = 1 };
+enum { VR_ACCUM_ITERATIVE = 0, VR_ACCUM_CLOSED_FORM = 1 };
+enum { VR_LAYOUT_LINEAR = 0, VR_LAYOUT_BRICKED = 1 };
+enum { VR_SYNTH_SPHERE_U8 = 0, VR_SYNTH_NOISE_BALL = 1 };
+
+/* quirk switches (SURVEY.md section 8(a) quirk list); default = VR_QUIRK_DEFAULT */
+enum {
+    VR_QUIRK_TRUNC_GRID = 1u << 0,   /* Q1: dispatch W/16 x H/16 groups, drop the rest
+                                        (src/RendererCore.cpp:121-122). Default OFF. */
+    VR_QUIRK_U16_OFFSET = 1u << 1,   /* Q10: +1000 on min/max for 16-bit data
+                                        (src/RendererCore.cpp:66-67,77-78). Default ON. */
+    VR_QUIRK_DEFAULT = VR_QUIRK_U16_OFFSET
+};
+
+/* ---- lifetime: RendererCore::RendererCore / ~RendererCore / setup()
+        (src/RendererCore.cpp:13-44; RendererGUI.cpp:38-40) ------------------- */
+/* device >= 0: HIP device ordinal.  device = -1: host-only handle (camera, file
+   parsing, transfer-function building work; every GPU operation fails loudly). */
+int vr_create(vr_handle *out, int device);
+void vr_destroy(vr_handle h);
+/* window_size / framebuffer_size + setup(): allocates the RGBA32F off-screen
+   target fb_w x fb_h in HBM (setupFBO, src/RendererCore.cpp:184-219). */
+int vr_setup(vr_handle h, int win_w, int win_h, int fb_w, int fb_h);
+const char *vr_last_error(vr_handle h);
+/* msg/title polling (src/RendererGUI.cpp:90-95): returns 1 and fills the buffers
+   if a message was pending (and clears it), 0 otherwise. */
+int vr_take_message(vr_handle h, char *title, size_t title_cap, char *msg, size_t msg_cap);
+
+/* ---- camera: Camera::setOrientation / resetCamera / setUBO
+        (src/Camera.cpp:30-151; bound at RendererGUI.cpp:42-46, :363) ---------- */
+int vr_camera_orient(vr_handle h, float zoom, float zenith, float azimuth);
+int vr_camera_reset(vr_handle h);
+int vr_camera_set_block(vr_handle h, const float block21[21]);
+int vr_camera_get_block(vr_handle h, float block21[21]);
+
+/* ---- shader: loadShader(fn, reload) (src/RendererCore.cpp:112-136;
+        RendererGUI.cpp:51,144,216).  The HIP kernel is built in; this records the
+        name (so `loaded_shader` is non-empty) and computes workgroups_x/y. ------ */
+int vr_load_shader(vr_handle h, const char *path, int reload);
+int vr_workgroups(vr_handle h, int *wg_x, int *wg_y);
+const char *vr_loaded_shader(vr_handle h);
+const char *vr_loaded_dataset(vr_handle h);
+
+/* ---- volume: readVolumeData / checkRawInfFile (src/RendererCore.cpp:46-54,
+        242-447; RendererGUI.cpp:196-197,209) --------------------------------- */
+int vr_check_raw_inf_file(vr_handle h, const char *path);          /* 1 = sidecar exists */
+/* tex3D_dim / voxel_size as typed into the raw-inf panel (RendererGUI.cpp:423-429):
+   used when a .raw has no .inf sidecar (the sidecar is then written). */
+int vr_set_dims(vr_handle h, int nx, int ny, int nz);
+int vr_set_spacing(vr_handle h, float sx, float sy, float sz);
+/* datasize_bytes = 1|2 (RendererGUI.cpp:128,134).  64-bit sizes throughout (F5). */
+int vr_read_volume_file(vr_handle h, const char *path, int datasize_bytes);
+/* memory-based loaders (new; the reference only loads files): host pointer is
+   copied, x fastest then y then z, host byte order. */
+int vr_set_volume(vr_handle h, const void *host_voxels, int nx, int ny, int nz,
+                  int datasize_bytes, float sx, float sy, float sz);
+/* generate a synthetic volume directly in HBM (never crosses PCIe).
+   kind = VR_SYNTH_SPHERE_U8 (param = radius in voxels) or VR_SYNTH_NOISE_BALL
+   (param = seed). */
+int vr_generate_synthetic(vr_handle h, int kind, int nx, int ny, int nz, int datasize_bytes,
+                          uint32_t param);
+/* copy the resident volume back to the host in x-fastest linear order */
+int vr_read_volume(vr_handle h, void *host_voxels, size_t bytes);
+int vr_get_dims(vr_handle h, int dims3[3], float spacing3[3], int *datasize_bytes);
+/* min_dataset_val / max_dataset_val (src/RendererCore.cpp:360-384) */
+int vr_get_dataset_range(vr_handle h, int *min_val, int *max_val);
+/* 256-bin display histogram (src/RendererCore.cpp:386-405) */
+int vr_histogram(vr_handle h, float hist256[256]);
+
+/* ---- uniforms: setAlpha / setMIP / setInitialCameraRotation / setMinVal /
+        setMaxVal (src/RendererCore.cpp:56-98; RendererGUI.cpp:336-358,382-385) -- */
+int vr_set_alpha(vr_handle h, float alpha_scale);
+int vr_set_mip(vr_handle h, int use_mip);
+int vr_set_view(vr_handle h, int rotate_to_top, int rotate_to_bottom); /* also resets camera */
+int vr_set_window(vr_handle h, int min_val, int max_val);
+int vr_get_window(vr_handle h, int *min_val, int *max_val);
+
+/* ---- build-defined switches (no reference equivalent) ---------------------- */
+int vr_set_filter(vr_handle h, int filter);          /* VR_FILTER_*  (F4)            */
+int vr_set_accum(vr_handle h, int accum);            /* VR_ACCUM_*   (Q8)            */
+int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*                   */
+int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_*; re-lays the volume out */
+int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
+/* kernel selection: 0 = automatic (specialised kernel when the configuration allows),
+   1 = always the generic line-by-line kernel (cross-check / debugging) */
+int vr_set_kernel_variant(vr_handle h, int variant);
+/* 1-D transfer function (N3): n knots of (iso in 0..255, r,g,b,a); n = 0 restores the
+   reference grey ramp.  Built with the natural cubic spline of src/CubicSpline.cpp. */
+int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n);
+int vr_get_transfer_lut(vr_handle h, float lut_rgba[256 * 4]);
+/* image-row shard rendered by this handle: global rows [row_begin,row_end); default all. */
+int vr_set_row_range(vr_handle h, int row_begin, int row_end);
+/* cyclic row stripes: this handle renders stripes s with s % count == index, each
+   `stripe_rows` rows tall (count = 1 disables). */
+int vr_set_row_stripes(vr_handle h, int stripe_rows, int index, int count);
+/* compact = 1: the target holds only this handle's rows, local row r of the shard at
+   offset r*fb_w (contiguous shard: r = row - row_begin; stripes: stripe-major).  Only
+   meaningful with an external target; vr_local_rows() gives its height in rows. */
+int vr_set_framebuffer_compact(vr_handle h, int compact);
+int vr_local_rows(vr_handle h);
+/* launch on a caller-owned HIP stream (hipStream_t as void*); NULL = own stream */
+int vr_set_stream(vr_handle h, void *hip_stream);
+/* render into a caller-owned device buffer of fb_w*fb_h*4 floats; NULL = own target */
+int vr_set_framebuffer_external(vr_handle h, void *device_rgba);
+
+/* ---- render(): src/RendererCore.cpp:138-163 (RendererGUI.cpp:101) ----------- */
+/* Launches the ray-march kernel into the off-screen target, times it with HIP
+   events and adds the ms to kerneltime_sum (blocking, like the reference's
+   GL_TIME_ELAPSED read-back). */
+int vr_render(vr_handle h);
+/* same launch without events or host synchronisation (for benches / graphs) */
+int vr_render_async(vr_handle h);
+int vr_synchronize(vr_handle h);
+/* kerneltime_sum read-and-zero (RendererGUI.cpp:58,60) */
+float vr_kernel_ms_take(vr_handle h);
+/* instrumented (untimed) launch: number of volume fetches per pixel / total */
+int vr_count_samples(vr_handle h, uint64_t *total, uint32_t *per_pixel, size_t n_pixels);
+void *vr_framebuffer_device(vr_handle h);
+int vr_read_pixels(vr_handle h, float *rgba, size_t n_floats);     /* D2H of the target */
+/* saveImage(fn, ext) (src/RendererCore.cpp:165-182): ext ".png" | ".bmp" | ".ppm" */
+int vr_save_image(vr_handle h, const char *path, const char *ext);
+
+/* name of the kernel variant the last vr_render* launched (for profiles/tests) */
+const char *vr_last_kernel_name(vr_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VR_CORE_H */

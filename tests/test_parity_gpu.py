@@ -1,0 +1,331 @@
+"""GPU parity: the HIP ray-march (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): <= 1e-4 per channel.  The build's own contract is
+stricter -- identical fp32 operation order -- so these tests ALSO assert bit-exact
+frames and identical per-pixel fetch counts; TOL is the fallback bar quoted in
+messages.  Everything here calls libvr_core.so; the oracle is only the checker.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def make_renderer(vra, size, **kw):
+    r = vra.RendererCore(0)
+    r.setup(size)
+    assert r.loadShader("VolumeRenderer.cs")
+    return r
+
+
+def assert_same(got, want, got_spp=None, want_spp=None, exact=True, what=""):
+    err = float(np.max(np.abs(got - want))) if got.size else 0.0
+    assert np.isfinite(got).all(), what
+    assert err <= TOL, f"{what}: max|diff|={err}"
+    if exact:
+        bad = got.view(np.uint32) != want.view(np.uint32)
+        assert not bad.any(), f"{what}: {int(bad.sum())} words differ bitwise (max|diff|={err})"
+    if got_spp is not None:
+        assert np.array_equal(got_spp, want_spp), f"{what}: per-pixel fetch counts differ"
+
+
+def rand_volume(rng, dims, dtype, smooth=False):
+    nx, ny, nz = dims
+    hi = 256 if dtype == np.uint8 else 4096
+    v = rng.integers(0, hi, size=(nz, ny, nx), dtype=np.int64)
+    if smooth:
+        z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        v = ((np.sin(x * 0.3) + np.cos(y * 0.23) + np.sin(z * 0.31) + 3) / 6 * (hi - 1)).astype(np.int64)
+    return v.astype(dtype)
+
+
+def orbit_blocks(oracle):
+    blocks = [("default", oracle.default_camera_block())]
+    c = oracle.Camera()
+    c.orient(0, 0.06 * 7, 0.06 * 9)
+    blocks.append(("orbit_a", c.block()))
+    c.orient(0, -0.06 * 15, 0.06 * 31)
+    blocks.append(("orbit_b", c.block()))
+    c = oracle.Camera()
+    c.orient(0, 0.0, -0.06 * 5)          # negative azimuth: exercises the Q13 wrap
+    blocks.append(("orbit_neg", c.block()))
+    c = oracle.Camera()
+    c.orient(0, -100.0, 0.3)             # zenith clamped to 0: straight down the pole
+    blocks.append(("pole", c.block()))
+    return blocks
+
+
+def test_cfg0_sphere_default_camera(vra, oracle):
+    """BASELINE config 0: 64^3 u8 sphere, 256x256."""
+    vol = oracle.gen_sphere_u8(64, 28)
+    with make_renderer(vra, (256, 256)) as r:
+        r.setVolume(vol)
+        r.render()
+        got = r.readPixels()
+        total, spp = r.countSamples(per_pixel=True)
+        assert r.last_kernel_name == "raymarch_fast_kernel"
+        assert r.kernelMsTake() > 0.0
+    want, want_total, want_spp = oracle.render(vol, oracle.OracleParams(256, 256), want_spp=True)
+    assert total == want_total
+    assert_same(got, want, spp, want_spp, what="cfg0")
+    # non-hit pixels are exactly (0,0,0,0) (Q12)
+    assert not got[0, 0].any() and not got[255, 255].any()
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+def test_noncubic_spacing_orbits(vra, oracle, dtype, variant):
+    """non-cubic dims + anisotropic spacing + odd image + orbit cameras"""
+    rng = np.random.default_rng(7)
+    dims = (40, 56, 24)
+    spacing = (1.0, 0.8, 1.7)
+    vol = rand_volume(rng, dims, dtype)
+    lo, hi = (10, 200) if dtype == np.uint8 else (100, 3000)
+    with make_renderer(vra, (173, 131)) as r:
+        r.setQuirks(0)
+        r.setKernelVariant(variant)
+        r.setVolume(vol, spacing)
+        r.setWindow(lo, hi)
+        for alpha in (1.0, 0.05):
+            r.setAlpha(alpha)
+            for name, block in orbit_blocks(oracle):
+                r.setCameraBlock(block)
+                r.render()
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                p = oracle.OracleParams(173, 131, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                assert_same(got, want, spp, want_spp, what=f"{name} alpha={alpha}")
+
+
+def test_camera_orbit_through_capi_matches_oracle_camera(vra, oracle):
+    """vr_camera_orient drives the same block the oracle's Camera restatement produces"""
+    with make_renderer(vra, (64, 64)) as r:
+        c = oracle.Camera()
+        for (zoom, dz, da) in [(0, 0.06, 0.06), (0, 0.06, -0.06), (1, 0, 0), (0, -0.12, 0.3), (-1, 0, 0), (0, -50, 0.1)]:
+            r.cameraOrient(zoom, dz, da)
+            c.orient(zoom, dz, da)
+            assert np.array_equal(r.getCameraBlock().view(np.uint32), c.block().view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", ["mip", "top", "bottom", "mip_top"])
+def test_mip_and_view_swizzles(vra, oracle, mode):
+    rng = np.random.default_rng(11)
+    dims = (33, 47, 29)
+    vol = rand_volume(rng, dims, np.uint8, smooth=True)
+    vol[3, 5, 7] = 255   # a bright voxel off-centre: orientation / z-flip sensitive
+    mip = "mip" in mode
+    top = "top" in mode
+    bottom = mode == "bottom"
+    with make_renderer(vra, (96, 80)) as r:
+        r.setVolume(vol, (1.0, 1.0, 1.3))
+        r.setMIP(mip)
+        r.setInitialCameraRotation(top, bottom)
+        r.setAlpha(0.6)
+        r.render()
+        got = r.readPixels()
+        _, spp = r.countSamples(per_pixel=True)
+    p = oracle.OracleParams(96, 80, alpha_scale=0.6, voxel_size=(1.0, 1.0, 1.3), is_mip=int(mip), view_top=int(top),
+                            view_bottom=int(bottom))
+    want, _, want_spp = oracle.render(vol, p, want_spp=True)
+    assert_same(got, want, spp, want_spp, what=mode)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+def test_trilinear_filter(vra, oracle, dtype):
+    rng = np.random.default_rng(3)
+    dims = (31, 20, 45)
+    vol = rand_volume(rng, dims, dtype)
+    lo, hi = (0, 255) if dtype == np.uint8 else (0, 4095)
+    with make_renderer(vra, (120, 90)) as r:
+        r.setQuirks(0)
+        r.setVolume(vol)
+        r.setWindow(lo, hi)
+        r.setFilter(1)
+        r.setAlpha(0.1)
+        for name, block in orbit_blocks(oracle)[:3]:
+            r.setCameraBlock(block)
+            r.render()
+            got = r.readPixels()
+            p = oracle.OracleParams(120, 90, cam=block, alpha_scale=0.1, min_val=lo, max_val=hi, filter=1)
+            want, _ = oracle.render(vol, p)
+            assert_same(got, want, what=f"trilinear {name}")
+
+
+def test_closed_form_accumulation(vra, oracle):
+    rng = np.random.default_rng(5)
+    vol = rand_volume(rng, (48, 48, 48), np.uint8)
+    with make_renderer(vra, (100, 100)) as r:
+        r.setVolume(vol)
+        r.setAccum(1)
+        r.setAlpha(0.03)
+        r.render()
+        got = r.readPixels()
+        _, spp = r.countSamples(per_pixel=True)
+    want, _, want_spp = oracle.render(vol, oracle.OracleParams(100, 100, alpha_scale=0.03, accum=1), want_spp=True)
+    assert_same(got, want, spp, want_spp, what="closed form")
+
+
+def test_transfer_function(vra, oracle):
+    rng = np.random.default_rng(9)
+    vol = rand_volume(rng, (36, 36, 36), np.uint8, smooth=True)
+    iso = [0, 141, 149, 255]   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59)
+    rgba = [[0, 0, 0, 0], [0.3, 0.5, 0.1, 0.759], [0.8, 0.2, 0.4, 0.45], [1, 1, 1, 1]]
+    with make_renderer(vra, (90, 70)) as r:
+        r.setVolume(vol)
+        r.setTransferFunction(iso, rgba)
+        lut = r.getTransferLut()
+        r.setAlpha(0.2)
+        r.render()
+        got = r.readPixels()
+    want_lut = oracle.spline_tf(iso, rgba)
+    assert np.array_equal(lut.view(np.uint32), want_lut.view(np.uint32))
+    want, _ = oracle.render(vol, oracle.OracleParams(90, 70, alpha_scale=0.2, tf_rgba=want_lut))
+    assert_same(got, want, what="transfer function")
+    assert not np.array_equal(got[..., 0], got[..., 1])   # colour TF really applied
+
+
+def test_bricked_layout_is_invisible(vra, oracle):
+    rng = np.random.default_rng(13)
+    dims = (37, 50, 23)          # not multiples of the 4^3 brick
+    vol = rand_volume(rng, dims, np.uint16)
+    with make_renderer(vra, (110, 77)) as r:
+        r.setQuirks(0)
+        r.setLayout(1)
+        r.setVolume(vol, (1.0, 1.1, 0.9))
+        r.setWindow(0, 4095)
+        assert np.array_equal(r.readVolume(), vol)
+        block = orbit_blocks(oracle)[1][1]
+        r.setCameraBlock(block)
+        r.render()
+        bricked = r.readPixels()
+        r.setLayout(0)                      # re-lay out in place
+        assert np.array_equal(r.readVolume(), vol)
+        r.render()
+        linear = r.readPixels()
+    p = oracle.OracleParams(110, 77, cam=block, voxel_size=(1.0, 1.1, 0.9), min_val=0, max_val=4095)
+    want, _ = oracle.render(vol, p)
+    assert_same(bricked, want, what="bricked")
+    assert_same(linear, want, what="linear after relayout")
+
+
+def test_quirks_trunc_grid_and_u16_offset(vra, oracle):
+    rng = np.random.default_rng(17)
+    vol = rand_volume(rng, (32, 32, 32), np.uint16)
+    with make_renderer(vra, (75, 53)) as r:      # 75 = 4*16+11, 53 = 3*16+5
+        r.setVolume(vol)
+        assert r.dataset_range == (int(vol.min()), int(vol.max()))
+        assert r.window == r.dataset_range       # default window = dataset range (RendererCore.cpp:375-378)
+        r.setQuirks(vra.renderer.QUIRK_TRUNC_GRID | vra.renderer.QUIRK_U16_OFFSET)
+        assert r.workgroups == (4, 3)
+        r.setWindow(-500, 2000)
+        r.render()
+        got = r.readPixels()
+    p = oracle.OracleParams(75, 53, min_val=500, max_val=3000, trunc_grid=1)   # +1000 (Q10)
+    want, _ = oracle.render(vol, p)
+    assert_same(got, want, what="quirks")
+    assert not got[:, 64:].any() and not got[48:, :].any()   # never written (Q1)
+
+
+def test_degenerate_window_and_inside_camera(vra, oracle):
+    rng = np.random.default_rng(19)
+    vol = rand_volume(rng, (24, 24, 24), np.uint8)
+    with make_renderer(vra, (64, 64)) as r:
+        r.setVolume(vol)
+        # Q4: max == min -> defined as 0 contribution everywhere
+        r.setWindow(77, 77)
+        r.render()
+        got = r.readPixels()
+        want, _ = oracle.render(vol, oracle.OracleParams(64, 64, min_val=77, max_val=77))
+        assert_same(got, want, what="min==max")
+        assert not got.any()
+        # Q5: camera dollied into the box (3 zoom-ins put the eye at the origin)
+        r.setWindow(0, 255)
+        r.setAlpha(0.02)
+        c = oracle.Camera()
+        for _ in range(3):
+            r.cameraOrient(1, 0, 0)
+            c.orient(1, 0, 0)
+        r.render()
+        got = r.readPixels()
+        _, spp = r.countSamples(per_pixel=True)
+        want, _, want_spp = oracle.render(vol, oracle.OracleParams(64, 64, cam=c.block(), alpha_scale=0.02), want_spp=True)
+        assert_same(got, want, spp, want_spp, what="inside camera")
+
+
+def test_row_shards_and_stripes_compose_to_full_frame(vra, oracle):
+    """multi-GPU decomposition: shards rendered separately == the full frame"""
+    vol = oracle.gen_noise_ball((48, 40, 44), 2, 0x9E3779B9)
+    W, H = 133, 101
+    with make_renderer(vra, (W, H)) as r:
+        r.setQuirks(0)
+        r.setVolume(vol)
+        r.setWindow(0, 4095)
+        r.setAlpha(0.05)
+        r.render()
+        full = r.readPixels()
+        want, _ = oracle.render(vol, oracle.OracleParams(W, H, alpha_scale=0.05, min_val=0, max_val=4095))
+        assert_same(full, want, what="full")
+        # contiguous row blocks, 3 ranks with a ragged last block
+        acc = np.zeros_like(full)
+        bounds = [0, 34, 68, H]
+        for k in range(3):
+            r.setRowRange(bounds[k], bounds[k + 1])
+            r.render()
+            part = r.readPixels()
+            acc[bounds[k]:bounds[k + 1]] = part[bounds[k]:bounds[k + 1]]
+        assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+        r.setRowRange(0, -1)
+    # cyclic stripes of 8 rows over 4 "ranks", each rank its own zeroed target
+    acc = np.zeros_like(full)
+    for k in range(4):
+        with make_renderer(vra, (W, H)) as r:
+            r.setQuirks(0)
+            r.setVolume(vol)
+            r.setWindow(0, 4095)
+            r.setAlpha(0.05)
+            r.setRowStripes(8, k, 4)
+            r.render()
+            part = r.readPixels()
+            rows = np.array([y for y in range(H) if (y // 8) % 4 == k])
+            other = np.array([y for y in range(H) if (y // 8) % 4 != k])
+            assert not part[other].any()
+            acc[rows] = part[rows]
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def test_device_generators_match_oracle_generators(vra, oracle):
+    with make_renderer(vra, (32, 32)) as r:
+        r.generateSynthetic(vra.renderer.SYNTH_SPHERE_U8, (64, 64, 64), 1, 28)
+        assert np.array_equal(r.readVolume(), oracle.gen_sphere_u8(64, 28))
+        for bpv in (1, 2):
+            r.generateSynthetic(vra.renderer.SYNTH_NOISE_BALL, (70, 45, 52), bpv, 0x9E3779B9)
+            assert np.array_equal(r.readVolume(), oracle.gen_noise_ball((70, 45, 52), bpv, 0x9E3779B9))
+        r.setLayout(1)
+        r.generateSynthetic(vra.renderer.SYNTH_NOISE_BALL, (70, 45, 52), 2, 123)
+        assert np.array_equal(r.readVolume(), oracle.gen_noise_ball((70, 45, 52), 2, 123))
+
+
+def test_histogram_matches_reference_formula(vra, oracle):
+    rng = np.random.default_rng(23)
+    vol = rand_volume(rng, (20, 30, 25), np.uint8)
+    with make_renderer(vra, (32, 32)) as r:
+        r.setVolume(vol)
+        h = r.histogram()
+    counts = np.bincount(vol.ravel(), minlength=256).astype(np.float64)
+    counts[0] = 0
+    want = (counts.astype(np.float32) * np.float32(100.0) / np.float32(counts.max())).astype(np.float32)
+    assert np.allclose(h, want, rtol=1e-6, atol=0)
+
+
+def test_render_requires_shader_and_dataset(vra):
+    r = vra.RendererCore(0)
+    r.setup((32, 32))
+    with pytest.raises(vra.VRError):
+        r.render()
+    r.loadShader("VolumeRenderer.cs")
+    with pytest.raises(vra.VRError):
+        r.render()
+    r.close()

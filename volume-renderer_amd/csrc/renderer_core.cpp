@@ -1,0 +1,637 @@
+// renderer_core.cpp -- see renderer_core.h.  Host side of the ray-march path:
+// owns the HBM objects (volume, RGBA32F target, transfer-function table), turns the
+// reference's uniform/UBO state into the kernel's FrameParams and launches it.
+// Compiled with -ffp-contract=off: buildFrame() repeats the fp32 operations of the
+// shader's main() (VolumeRenderer.cs:62-83,109) in the shader's order.
+#include "renderer_core.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "volume_io.h"
+#include "vr_kernels.h"
+
+namespace vr {
+
+namespace {
+constexpr uint32_t kQuirkTruncGrid = 1u << 0, kQuirkU16Offset = 1u << 1;
+constexpr int kLocalSize = 16;   // layout(local_size_x = 16, local_size_y = 16), VolumeRenderer.cs:3
+}  // namespace
+
+RendererCore::RendererCore(int device) : main_cam(30), histogram(256, 0.0f), device_(device)
+{
+    if (device_ >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) throw NoDeviceError("no HIP device available");
+        if (device_ >= n) throw NoDeviceError("HIP device ordinal out of range");
+        check(hipSetDevice(device_), "hipSetDevice");
+        check(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking), "hipStreamCreate");
+        check(hipEventCreate(&ev0_), "hipEventCreate");
+        check(hipEventCreate(&ev1_), "hipEventCreate");
+        check(hipMalloc(&d_scratch_, sizeof(unsigned) * 260), "hipMalloc(scratch)");
+    }
+}
+
+RendererCore::~RendererCore()
+{
+    if (device_ >= 0) {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream());
+        freeVolume();
+        if (d_fb_) (void)hipFree(d_fb_);
+        if (d_tf_) (void)hipFree(d_tf_);
+        if (d_spp_) (void)hipFree(d_spp_);
+        if (d_scratch_) (void)hipFree(d_scratch_);
+        if (ev0_) (void)hipEventDestroy(ev0_);
+        if (ev1_) (void)hipEventDestroy(ev1_);
+        if (own_stream_) (void)hipStreamDestroy(own_stream_);
+    }
+}
+
+void RendererCore::requireDevice(const char *what) const
+{
+    if (device_ < 0) throw NoDeviceError(std::string(what) + ": host-only handle, no HIP device");
+    hipError_t e = hipSetDevice(device_);
+    if (e != hipSuccess) throw HipError(e, std::string("hipSetDevice: ") + hipGetErrorString(e));
+}
+
+void RendererCore::check(hipError_t e, const char *what) const
+{
+    if (e != hipSuccess) throw HipError(e, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---------------------------------------------------------------- setup / FBO / UBO
+void RendererCore::setup()
+{
+    setupFBO();
+}
+
+void RendererCore::setupFBO()
+{
+    if (framebuffer_size[0] <= 0 || framebuffer_size[1] <= 0)
+        throw std::runtime_error("Framebuffer not complete. Error code: zero-sized framebuffer");
+    if (device_ < 0) return;   // host-only handle: nothing to allocate
+    requireDevice("setupFBO");
+    if (d_fb_) { check(hipFree(d_fb_), "hipFree(fb)"); d_fb_ = nullptr; }
+    const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1];
+    check(hipMalloc(reinterpret_cast<void **>(&d_fb_), n * sizeof(float4)), "hipMalloc(framebuffer)");
+    check(hipMemsetAsync(d_fb_, 0, n * sizeof(float4), stream()), "hipMemset(framebuffer)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+}
+
+void RendererCore::setupUBO(bool)
+{
+    cam_block_.clear();
+    main_cam.setUBO(cam_block_);
+}
+
+// ---------------------------------------------------------------- uniforms
+void RendererCore::setAlpha()
+{
+    if (cs_program_) u_.alpha_scale = alpha_scale;
+}
+
+void RendererCore::setMinVal()
+{
+    if (cs_program_) u_.min_val = (datasize_bytes == 2 && (quirks & kQuirkU16Offset)) ? min_val + 1000 : min_val;
+}
+
+void RendererCore::setMaxVal()
+{
+    if (cs_program_) u_.max_val = (datasize_bytes == 2 && (quirks & kQuirkU16Offset)) ? max_val + 1000 : max_val;
+}
+
+void RendererCore::setMIP()
+{
+    if (cs_program_) u_.is_MIP = use_mip ? 1 : 0;
+}
+
+void RendererCore::setInitialCameraRotation()
+{
+    if (cs_program_) {
+        main_cam.resetCamera();
+        main_cam.is_changed = true;
+        u_.view_top = rotate_to_top ? 1 : 0;
+        u_.view_bottom = rotate_to_bottom ? 1 : 0;
+    }
+}
+
+void RendererCore::setUniforms()
+{
+    if (cs_program_) {
+        u_.voxel_size[0] = voxel_size[0];
+        u_.voxel_size[1] = voxel_size[1];
+        u_.voxel_size[2] = voxel_size[2];
+    }
+    setAlpha();
+    setMinVal();
+    setMaxVal();
+    setMIP();
+    setInitialCameraRotation();
+}
+
+bool RendererCore::loadShader(std::string fn, bool reload)
+{
+    // The kernel is compiled into this library; `fn` is only recorded so the GUI's
+    // "shader loaded" state (RendererGUI.cpp:150) behaves the same.
+    if (reload) fn = loaded_shader;
+    if (fn.empty()) {
+        setMessage("Error!", "Failed to open Shader file.");
+        loaded_shader.clear();
+        return false;
+    }
+    const size_t idx = fn.find_last_of('/');
+    loaded_shader = idx == std::string::npos ? fn : fn.substr(idx + 1);
+    cs_program_ = true;
+    if (quirks & kQuirkTruncGrid) {
+        workgroups_x = window_size[0] / kLocalSize;   // src/RendererCore.cpp:121-122
+        workgroups_y = window_size[1] / kLocalSize;
+    } else {
+        workgroups_x = (window_size[0] + kLocalSize - 1) / kLocalSize;
+        workgroups_y = (window_size[1] + kLocalSize - 1) / kLocalSize;
+    }
+    u_.alpha_scale = alpha_scale;
+    if (!loaded_dataset.empty()) {
+        setUniforms();
+        main_cam.resetCamera();
+        main_cam.is_changed = true;
+    }
+    setMessage("Shader Loaded!", "Shader Loaded Successfully!");
+    return true;
+}
+
+// ---------------------------------------------------------------- volume
+size_t RendererCore::storageVoxels(int nx, int ny, int nz, int lay) const
+{
+    if (lay == 0) return (size_t)nx * (size_t)ny * (size_t)nz;
+    return (size_t)((nx + 3) / 4) * (size_t)((ny + 3) / 4) * (size_t)((nz + 3) / 4) * 64u;
+}
+
+void RendererCore::freeVolume()
+{
+    if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
+}
+
+void RendererCore::allocVolume(int nx, int ny, int nz, int bytes, int lay)
+{
+    requireDevice("volume upload");
+    freeVolume();
+    // + one x/y slab of slack so a one-past-the-edge index can never fault
+    const size_t need = (storageVoxels(nx, ny, nz, lay) + (size_t)nx * (size_t)ny + 256) * (size_t)bytes;
+    check(hipMalloc(&d_vol_, need), "hipMalloc(volume)");
+    vol_alloc_bytes_ = need;
+    vol_layout_ = lay;
+    if (lay != 0) check(hipMemsetAsync(d_vol_, 0, need, stream()), "hipMemset(volume)");
+}
+
+void RendererCore::setVolume(const void *host, int nx, int ny, int nz, int bytes, float sx, float sy, float sz)
+{
+    if (!host || nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2))
+        throw std::invalid_argument("setVolume: bad dimensions or datasize_bytes");
+    requireDevice("setVolume");
+    const size_t lin_bytes = (size_t)nx * (size_t)ny * (size_t)nz * (size_t)bytes;
+    const uint32_t bnx = (uint32_t)((nx + 3) / 4), bny = (uint32_t)((ny + 3) / 4);
+    if (layout == 0) {
+        allocVolume(nx, ny, nz, bytes, 0);
+        check(hipMemcpyAsync(d_vol_, host, lin_bytes, hipMemcpyHostToDevice, stream()), "hipMemcpy(volume)");
+    } else {
+        void *staging = nullptr;
+        check(hipMalloc(&staging, lin_bytes), "hipMalloc(staging)");
+        hipError_t e = hipMemcpyAsync(staging, host, lin_bytes, hipMemcpyHostToDevice, stream());
+        if (e == hipSuccess) {
+            try { allocVolume(nx, ny, nz, bytes, 1); } catch (...) { (void)hipFree(staging); throw; }
+            e = launch_relayout(staging, d_vol_, bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, bnx, bny, 0, stream());
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream());
+        (void)hipFree(staging);
+        check(e, "volume relayout");
+    }
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
+    voxel_size[0] = sx; voxel_size[1] = sy; voxel_size[2] = sz;
+    datasize_bytes = bytes;
+    afterVolumeLoaded("<memory>");
+}
+
+void RendererCore::generateSynthetic(int kind, int nx, int ny, int nz, int bytes, uint32_t param)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2) || (kind != 0 && kind != 1) ||
+        (kind == 0 && bytes != 1))
+        throw std::invalid_argument("generateSynthetic: bad arguments");
+    requireDevice("generateSynthetic");
+    allocVolume(nx, ny, nz, bytes, layout);
+    check(launch_gen_volume(d_vol_, bytes, kind, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, param, layout,
+                            (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), stream()),
+          "gen_volume_kernel");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
+    voxel_size[0] = voxel_size[1] = voxel_size[2] = 1.0f;
+    datasize_bytes = bytes;
+    afterVolumeLoaded(kind == 0 ? "<synthetic sphere>" : "<synthetic noise ball>");
+}
+
+void RendererCore::readVolume(void *host, size_t bytes)
+{
+    requireDevice("readVolume");
+    if (!d_vol_) throw std::runtime_error("readVolume: no dataset loaded");
+    const size_t lin_bytes = (size_t)tex3D_dim[0] * tex3D_dim[1] * tex3D_dim[2] * (size_t)datasize_bytes;
+    if (!host || bytes < lin_bytes) throw std::invalid_argument("readVolume: buffer too small");
+    if (vol_layout_ == 0) {
+        check(hipMemcpyAsync(host, d_vol_, lin_bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H volume)");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        return;
+    }
+    void *staging = nullptr;
+    check(hipMalloc(&staging, lin_bytes), "hipMalloc(staging)");
+    hipError_t e = launch_relayout(d_vol_, staging, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1],
+                                   (uint32_t)tex3D_dim[2], (uint32_t)((tex3D_dim[0] + 3) / 4),
+                                   (uint32_t)((tex3D_dim[1] + 3) / 4), 1, stream());
+    if (e == hipSuccess) e = hipMemcpyAsync(host, staging, lin_bytes, hipMemcpyDeviceToHost, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    (void)hipFree(staging);
+    check(e, "readVolume");
+}
+
+void RendererCore::setLayout(int lay)
+{
+    if (lay != 0 && lay != 1) throw std::invalid_argument("setLayout: unknown layout");
+    layout = lay;
+    if (!d_vol_ || vol_layout_ == lay) return;
+    requireDevice("setLayout");
+    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    void *old = d_vol_;
+    d_vol_ = nullptr;
+    try { allocVolume(nx, ny, nz, datasize_bytes, lay); } catch (...) { d_vol_ = old; throw; }
+    hipError_t e = launch_relayout(old, d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz,
+                                   (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), lay == 0 ? 1 : 0, stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(stream());
+    (void)hipFree(old);
+    check(e, "relayout");
+}
+
+// min/max scan of src/RendererCore.cpp:360-384 as a device reduction
+void RendererCore::scanDatasetRange()
+{
+    if (datasize_bytes == 2) {
+        const unsigned init[2] = {0xffffffffu, 0u};
+        check(hipMemcpyAsync(d_scratch_, init, sizeof(init), hipMemcpyHostToDevice, stream()), "hipMemcpy(scratch)");
+        check(launch_stats(d_vol_, 2, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
+                           vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 0,
+                           1.0f, d_scratch_, d_scratch_ + 2, stream()),
+              "stats_kernel");
+        unsigned mm[2];
+        check(hipMemcpyAsync(mm, d_scratch_, sizeof(mm), hipMemcpyDeviceToHost, stream()), "hipMemcpy(scratch)");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        // reference initial values: max_value = -1, min_value = 9000000
+        const int mx = mm[1] == 0u && mm[0] == 0xffffffffu ? -1 : (int)mm[1];
+        const int mn = mm[0] == 0xffffffffu ? 9000000 : (int)mm[0];
+        max_val = max_dataset_val = mx;
+        min_val = min_dataset_val = mn;
+    } else {
+        min_val = min_dataset_val = 0;
+        max_val = max_dataset_val = 255;
+    }
+}
+
+void RendererCore::computeHistogram(float out[256])
+{
+    requireDevice("histogram");
+    if (!d_vol_) throw std::runtime_error("histogram: no dataset loaded");
+    check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned) * 260, stream()), "hipMemset(scratch)");
+    check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
+                       vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 1,
+                       (float)max_dataset_val, d_scratch_, d_scratch_ + 2, stream()),
+          "stats_kernel");
+    unsigned counts[256];
+    check(hipMemcpyAsync(counts, d_scratch_ + 2, sizeof(counts), hipMemcpyDeviceToHost, stream()), "hipMemcpy(hist)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    // src/RendererCore.cpp:361,400-405: the normaliser starts from the dataset max
+    // (16-bit) or -1 (8-bit) and is raised to the largest bin count
+    double max_value = datasize_bytes == 2 ? (double)max_dataset_val : -1.0;
+    for (int i = 1; i < 256; i++) max_value = std::max(max_value, (double)counts[i]);
+    for (int i = 0; i < 256; i++) {
+        histogram[i] = i == 0 ? 0.0f : (float)counts[i] * 100.0f / (float)max_value;
+        out[i] = histogram[i];
+    }
+}
+
+void RendererCore::afterVolumeLoaded(const std::string &name)
+{
+    scanDatasetRange();
+    setMessage("File Loaded!", "File Loaded Successfully!");
+    if (!loaded_shader.empty()) {
+        setUniforms();
+        main_cam.resetCamera();
+        main_cam.is_changed = true;
+    }
+    const size_t idx = name.find_last_of('/');
+    loaded_dataset = idx == std::string::npos ? name : name.substr(idx + 1);
+}
+
+bool RendererCore::checkRawInfFile(std::string fn)
+{
+    std::ifstream inf_file(fn + ".inf");
+    return bool(inf_file);
+}
+
+void RendererCore::readVolumeData(std::string fn)
+{
+    if (fn.size() < 3) { setMessage("Error!", "Failed to Open RAW file..."); return; }
+    if (datasize_bytes != 1 && datasize_bytes != 2) {
+        setMessage("Error!", "Select the data size (UINT8/UINT16) before loading a dataset.");
+        return;
+    }
+    const std::string ext = fn.substr(fn.length() - 3, 3);
+    std::vector<uint8_t> voxels;
+    int dims[3];
+    float spacing[3];
+    if (ext == "raw") {
+        if (checkRawInfFile(fn)) {
+            RawInf inf;
+            std::string t, m;
+            if (!parseRawInf(fn + ".inf", inf, t, m)) { setMessage(t, m); return; }
+            for (int i = 0; i < 3; i++) { dims[i] = inf.dims[i]; spacing[i] = inf.spacing[i]; }
+        } else {
+            // no sidecar: use the values typed into the GUI and write one (:304-317)
+            for (int i = 0; i < 3; i++) { dims[i] = tex3D_dim[i]; spacing[i] = voxel_size[i]; }
+            writeRawInf(fn + ".inf", dims, spacing);
+        }
+        const uint64_t len = (uint64_t)std::max(dims[0], 0) * (uint64_t)std::max(dims[1], 0) * (uint64_t)std::max(dims[2], 0);
+        {
+            std::ifstream probe(fn, std::ios::binary);
+            if (!probe) { setMessage("Error!", "Failed to Open RAW file..."); return; }
+        }
+        if (len == 0) {
+            setMessage("Invalid Data Size!",
+                       "Texture Dimensions shouldn't contain any zeroes. Please provide a valid .raw.inf file.");
+            return;
+        }
+        if (!readRawFile(fn, len * (uint64_t)datasize_bytes, voxels)) {
+            setMessage("Error!", "Failed to Open RAW file...");
+            return;
+        }
+    } else {
+        PvmVolume pvm;
+        std::string err;
+        if (!readPVMvolume(fn, pvm, err)) { setMessage("Error!", "Error reading PVM file"); last_error = err; return; }
+        dims[0] = (int)pvm.width; dims[1] = (int)pvm.height; dims[2] = (int)pvm.depth;
+        spacing[0] = pvm.scalex; spacing[1] = pvm.scaley; spacing[2] = pvm.scalez;
+        if ((int)pvm.components != datasize_bytes) {
+            // the reference reinterprets the payload with the GUI-selected size and
+            // reads out of bounds when they disagree; refuse instead
+            setMessage("Error!", "Error reading PVM file");
+            last_error = "PVM component count does not match datasize_bytes";
+            return;
+        }
+        voxels.swap(pvm.data);   // Q9: 16-bit payload bytes are taken in host order, no swap (:347,368,393)
+    }
+    std::cout << "Dataset dimensions: " << dims[0] << ", " << dims[1] << ", " << dims[2] << std::endl;
+    std::cout << "Dataset Aspect ratio: " << spacing[0] << ", " << spacing[1] << ", " << spacing[2] << std::endl;
+    const int bytes = datasize_bytes;
+    setVolume(voxels.data(), dims[0], dims[1], dims[2], bytes, spacing[0], spacing[1], spacing[2]);
+    const size_t idx = fn.find_last_of('/');
+    loaded_dataset = idx == std::string::npos ? fn : fn.substr(idx + 1);
+}
+
+// ---------------------------------------------------------------- transfer function
+void RendererCore::setTransferFunction(const int32_t *iso, const float *rgba4, int n)
+{
+    if (n == 0) {
+        tf_lut_.clear();
+        return;
+    }
+    std::vector<float> lut;
+    if (!iso || !rgba4 || !buildSplineLUT(iso, rgba4, n, lut))
+        throw std::invalid_argument("setTransferFunction: need >= 2 knots with ascending iso values");
+    tf_lut_.swap(lut);
+    if (device_ >= 0) {
+        requireDevice("setTransferFunction");
+        if (!d_tf_) check(hipMalloc(reinterpret_cast<void **>(&d_tf_), 256 * sizeof(float4)), "hipMalloc(tf)");
+        check(hipMemcpyAsync(d_tf_, tf_lut_.data(), 256 * sizeof(float4), hipMemcpyHostToDevice, stream()), "hipMemcpy(tf)");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    }
+}
+
+void RendererCore::getTransferLut(float *lut) const
+{
+    if (tf_lut_.empty()) {
+        for (int i = 0; i < 256; i++) lut[4 * i] = lut[4 * i + 1] = lut[4 * i + 2] = lut[4 * i + 3] = (float)i / 255.0f;
+    } else {
+        std::memcpy(lut, tf_lut_.data(), sizeof(float) * 1024);
+    }
+}
+
+// ---------------------------------------------------------------- render
+void RendererCore::setRowStripes(int rows, int index, int count)
+{
+    if (count < 1 || index < 0 || index >= count || (count > 1 && rows < 1))
+        throw std::invalid_argument("setRowStripes: bad stripe spec");
+    stripe_rows_ = rows; stripe_index_ = index; stripe_count_ = count;
+}
+
+int RendererCore::localRows() const
+{
+    const int h = framebuffer_size[1];
+    if (stripe_count_ > 1) {
+        const int total = (h + stripe_rows_ - 1) / stripe_rows_;
+        const int mine = (total - stripe_index_ + stripe_count_ - 1) / stripe_count_;
+        return mine * stripe_rows_;
+    }
+    const int b = std::max(0, row_begin_), e = row_end_ < 0 ? h : std::min(row_end_, h);
+    return std::max(0, e - b);
+}
+
+bool RendererCore::certifyDivisor(float b)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &b, 4);
+    auto it = cert_cache_.find(bits);
+    if (it != cert_cache_.end()) return it->second;
+    bool ok = false;
+    if (std::isfinite(b) && b > 1e-30f && b < 1e30f) {
+        const float r = 1.0f / b;
+        check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned), stream()), "hipMemset(scratch)");
+        check(launch_certify_div(b, r, d_scratch_, stream()), "certify_div_kernel");
+        unsigned bad = 1;
+        check(hipMemcpyAsync(&bad, d_scratch_, sizeof(unsigned), hipMemcpyDeviceToHost, stream()), "hipMemcpy(scratch)");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        ok = (bad == 0);
+    }
+    cert_cache_[bits] = ok;
+    return ok;
+}
+
+void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
+{
+    std::memset(&P, 0, sizeof(P));
+    if (cam_block_.size() != 21 || main_cam.is_changed) setupUBO(true);
+    std::memcpy(P.cam, cam_block_.data(), sizeof(float) * 21);
+    P.img_w = framebuffer_size[0];
+    P.img_h = framebuffer_size[1];
+    P.row_begin = std::max(0, row_begin_);
+    P.row_end = row_end_ < 0 ? P.img_h : std::min(row_end_, P.img_h);
+    if (quirks & kQuirkTruncGrid) {
+        P.col_lim = (P.img_w / kLocalSize) * kLocalSize;
+        P.row_lim = (P.img_h / kLocalSize) * kLocalSize;
+    } else {
+        P.col_lim = P.img_w;
+        P.row_lim = P.img_h;
+    }
+    P.stripe_rows = stripe_count_ > 1 ? stripe_rows_ : 1;
+    P.stripe_index = stripe_index_;
+    P.stripe_count = stripe_count_;
+    P.fb_compact = fb_compact_ ? 1 : 0;
+    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    P.nx = nx; P.ny = ny; P.nz = nz;
+    P.fdim[0] = (float)nx; P.fdim[1] = (float)ny; P.fdim[2] = (float)nz;
+    P.bnx = (nx + 3) / 4; P.bny = (ny + 3) / 4; P.bnz = (nz + 3) / 4;
+    // ---- main(): VolumeRenderer.cs:65-83
+    int max_dim = std::max(nx, ny);
+    max_dim = std::max(max_dim, nz);
+    const bool swz = (u_.view_bottom == 1 || u_.view_top == 1);
+    const float d0 = (float)nx, d1 = swz ? (float)nz : (float)ny, d2 = swz ? (float)ny : (float)nz;
+    const float s0 = u_.voxel_size[0], s1 = swz ? u_.voxel_size[2] : u_.voxel_size[1],
+                s2 = swz ? u_.voxel_size[1] : u_.voxel_size[2];
+    const float fmax_dim = (float)max_dim;
+    const float pm[3] = {(d0 / fmax_dim) * s0, (d1 / fmax_dim) * s1, (d2 / fmax_dim) * s2};
+    for (int i = 0; i < 3; i++) {
+        P.half[i] = pm[i] / 2.0f;
+        P.pmin[i] = 0.0f - P.half[i];
+        P.pmax[i] = pm[i] - P.half[i];
+        P.ext[i] = P.pmax[i] + P.half[i];
+        P.rext[i] = 1.0f / P.ext[i];
+    }
+    // ---- step_size: VolumeRenderer.cs:109 (composite, .xzy) / :146 (MIP, .xyz)
+    const float e0 = P.pmax[0] - P.pmin[0], e1 = P.pmax[1] - P.pmin[1], e2 = P.pmax[2] - P.pmin[2];
+    const float num = std::sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
+    const float den = u_.is_MIP == 1 ? std::sqrt((fx * fx + fy * fy) + fz * fz) : std::sqrt((fx * fx + fz * fz) + fy * fy);
+    P.step = num / den;
+    P.alpha_scale = u_.alpha_scale;
+    P.min_val = u_.min_val; P.max_val = u_.max_val;
+    P.fmin = (float)u_.min_val; P.fmax = (float)u_.max_val;
+    P.fden = (float)(u_.max_val - u_.min_val);
+    P.rden = P.fden != 0.0f ? 1.0f / P.fden : 0.0f;
+    P.view_top = u_.view_top; P.view_bottom = u_.view_bottom;
+    P.max_steps = 10000;   // VolumeRenderer.cs:115
+    P.accum = accum;
+    P.tf_len = tf_lut_.empty() ? 0 : 256;
+    P.skip_empty = skip_empty;
+
+    L.bytes_per_voxel = datasize_bytes;
+    L.filter = filter;
+    L.mip = u_.is_MIP;
+    L.layout = vol_layout_;
+    L.generic = force_generic;
+    // division strategy: unit extents need no division at all; other divisors use the
+    // 3-op Markstein quotient only after an exhaustive on-device certification
+    const bool unit = P.ext[0] == 1.0f && P.ext[1] == 1.0f && P.ext[2] == 1.0f;
+    if (unit) L.divmode_tc = DIV_UNIT;
+    else L.divmode_tc = (certifyDivisor(P.ext[0]) && certifyDivisor(P.ext[1]) && certifyDivisor(P.ext[2])) ? DIV_CERT : DIV_EXACT;
+    L.divmode_win = (P.fden > 0.0f && certifyDivisor(P.fden)) ? DIV_CERT : DIV_EXACT;
+}
+
+void RendererCore::launch(uint32_t *spp)
+{
+    requireDevice("render");
+    if (!cs_program_) throw std::runtime_error("render: no shader loaded (call loadShader first)");
+    if (!d_vol_) throw std::runtime_error("render: no dataset loaded");
+    float4 *fb = ext_fb_ ? reinterpret_cast<float4 *>(ext_fb_) : d_fb_;
+    if (!fb) throw std::runtime_error("render: setup() has not allocated the framebuffer");
+    FrameParams P;
+    LaunchConfig L;
+    buildFrame(P, L);
+    check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
+}
+
+void RendererCore::render()
+{
+    requireDevice("render");
+    // the reference brackets glDispatchCompute with a GL_TIME_ELAPSED query and blocks
+    // on its result (src/RendererCore.cpp:149-153); same shape with HIP events
+    FrameParams P;   // certify (may sync) before the timed region
+    LaunchConfig L;
+    if (cs_program_ && d_vol_) buildFrame(P, L);
+    check(hipEventRecord(ev0_, stream()), "hipEventRecord");
+    launch(nullptr);
+    check(hipEventRecord(ev1_, stream()), "hipEventRecord");
+    check(hipEventSynchronize(ev1_), "hipEventSynchronize");
+    float ms = 0.0f;
+    check(hipEventElapsedTime(&ms, ev0_, ev1_), "hipEventElapsedTime");
+    kerneltime_sum += ms;
+}
+
+void RendererCore::renderAsync()
+{
+    launch(nullptr);
+}
+
+void RendererCore::synchronize()
+{
+    requireDevice("synchronize");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+}
+
+void RendererCore::countSamples(uint64_t *total, uint32_t *per_pixel, size_t n_pixels)
+{
+    requireDevice("countSamples");
+    const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1];
+    if (per_pixel && n_pixels < n) throw std::invalid_argument("countSamples: per_pixel buffer too small");
+    if (spp_capacity_ < n) {
+        if (d_spp_) { check(hipFree(d_spp_), "hipFree(spp)"); d_spp_ = nullptr; }
+        check(hipMalloc(reinterpret_cast<void **>(&d_spp_), n * sizeof(uint32_t)), "hipMalloc(spp)");
+        spp_capacity_ = n;
+    }
+    check(hipMemsetAsync(d_spp_, 0, n * sizeof(uint32_t), stream()), "hipMemset(spp)");
+    launch(d_spp_);
+    std::vector<uint32_t> host(n);
+    check(hipMemcpyAsync(host.data(), d_spp_, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream()), "hipMemcpy(spp)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    uint64_t sum = 0;
+    for (uint32_t v : host) sum += v;
+    if (total) *total = sum;
+    if (per_pixel) std::memcpy(per_pixel, host.data(), n * sizeof(uint32_t));
+}
+
+void RendererCore::readPixels(float *rgba, size_t n_floats)
+{
+    requireDevice("readPixels");
+    const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1] * 4;
+    if (!rgba || n_floats < n) throw std::invalid_argument("readPixels: buffer too small");
+    const void *src = framebufferDevice();
+    if (!src) throw std::runtime_error("readPixels: no framebuffer");
+    check(hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H framebuffer)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+}
+
+// src/RendererCore.cpp:165-182: RGB8 read-back of the target, written top row first
+// (stbi_flip_vertically_on_write).  glReadPixels' float->unorm8 conversion is
+// round(clamp(c,0,1)*255).
+bool RendererCore::saveImage(std::string fn, std::string ext)
+{
+    const int w = framebuffer_size[0], h = framebuffer_size[1];
+    std::vector<float> rgba((size_t)w * h * 4);
+    readPixels(rgba.data(), rgba.size());
+    const int stride = w * 3;
+    std::vector<uint8_t> rgb((size_t)stride * h);
+    for (int y = 0; y < h; y++) {
+        const float *src = &rgba[(size_t)(h - 1 - y) * w * 4];
+        uint8_t *dst = &rgb[(size_t)y * stride];
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++) {
+                float v = src[4 * x + c];
+                v = v != v ? 0.0f : std::fmin(std::fmax(v, 0.0f), 1.0f);
+                dst[3 * x + c] = (uint8_t)std::floor(v * 255.0f + 0.5f);
+            }
+    }
+    if (ext == ".png") return writePNG(fn, w, h, rgb.data(), stride);
+    if (ext == ".bmp") return writeBMP(fn, w, h, rgb.data(), stride);
+    if (ext == ".ppm") return writePPM(fn, w, h, rgb.data(), stride);
+    return false;   // ".jpg" (stb) is not provided
+}
+
+}  // namespace vr

@@ -1,0 +1,137 @@
+// renderer_core.h -- host side of the MI355X ray-march path.
+//
+// Mirrors the reference's RendererCore (include/RendererCore.h:9-44): same member
+// and method names, same call semantics, with the OpenGL objects replaced by HIP
+// allocations and the compute-shader dispatch replaced by vr::launch_raymarch.
+// Members the reference keeps private-but-friend (RendererGUI pokes them directly,
+// include/RendererCore.h:18) are public here; vr_capi.cpp is the "friend".
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "camera.h"
+#include "vr_frame.h"
+
+namespace vr {
+
+struct HipError : std::runtime_error {
+    hipError_t code;
+    HipError(hipError_t c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+struct NoDeviceError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct IoError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+class RendererCore {
+public:
+    explicit RendererCore(int device);      // device < 0: host-only (no HIP calls ever)
+    ~RendererCore();
+    RendererCore(const RendererCore &) = delete;
+    RendererCore &operator=(const RendererCore &) = delete;
+
+    void setup();                            // src/RendererCore.cpp:34-44
+    void render();                           // src/RendererCore.cpp:138-163 (timed, blocking)
+    void renderAsync();                      // same launch, no events / no host sync
+    void synchronize();
+
+    // ---- reference-named members (private+friend in the reference)
+    void setAlpha();                         // :56-60
+    void setMinVal();                        // :62-71
+    void setMaxVal();                        // :73-82
+    void setMIP();                           // :84-88
+    void setUniforms();                      // :100-110
+    void setInitialCameraRotation();         // :90-98
+    void setupFBO();                         // :184-219
+    void setupUBO(bool is_update = false);   // :221-240
+    void readVolumeData(std::string fn);     // :242-447
+    bool checkRawInfFile(std::string fn);    // :46-54
+    bool saveImage(std::string fn, std::string ext);  // :165-182
+    bool loadShader(std::string fn, bool reload);     // :112-136
+
+    Camera main_cam;
+    std::vector<float> histogram;
+    std::string loaded_dataset, loaded_shader, msg, title;
+    float alpha_scale = 1, kerneltime_sum = 0;
+    int workgroups_x = 0, workgroups_y = 0, datasize_bytes = -1, min_val = 0, max_val = 0, max_dataset_val = 0,
+        min_dataset_val = 0;
+    bool use_mip = false, rotate_to_bottom = false, rotate_to_top = false;
+    float voxel_size[3] = {1.0f, 1.0f, 1.0f};
+    int tex3D_dim[3] = {0, 0, 0};
+    int window_size[2] = {0, 0}, framebuffer_size[2] = {0, 0};
+
+    // ---- additions (no reference equivalent)
+    void setVolume(const void *host, int nx, int ny, int nz, int bytes, float sx, float sy, float sz);
+    void generateSynthetic(int kind, int nx, int ny, int nz, int bytes, uint32_t param);
+    void readVolume(void *host, size_t bytes);
+    void setLayout(int layout);
+    void setTransferFunction(const int32_t *iso, const float *rgba4, int n);
+    void getTransferLut(float *lut1024) const;
+    void countSamples(uint64_t *total, uint32_t *per_pixel, size_t n_pixels);
+    void readPixels(float *rgba, size_t n_floats);
+    void *framebufferDevice() const { return ext_fb_ ? ext_fb_ : d_fb_; }
+    void setStream(hipStream_t s) { user_stream_ = s; }
+    void setExternalFramebuffer(void *p) { ext_fb_ = p; }
+    void setRowRange(int b, int e) { row_begin_ = b; row_end_ = e; }
+    void setRowStripes(int rows, int index, int count);
+    void setFramebufferCompact(bool on) { fb_compact_ = on; }
+    int localRows() const;   // rows this handle renders (stripe padding included)
+    void computeHistogram(float out[256]);
+    const char *lastKernelName() const { return last_kernel_; }
+    bool hasDevice() const { return device_ >= 0; }
+
+    int filter = 0, accum = 0, layout = 0, skip_empty = 0;
+    uint32_t quirks = 2u;   // VR_QUIRK_DEFAULT
+    int force_generic = 0;
+    std::string last_error;
+
+private:
+    // the values the kernel sees: the reference's GL uniform state (set by set*())
+    struct Uniforms {
+        float alpha_scale = 1;
+        float voxel_size[3] = {1, 1, 1};
+        int min_val = 0, max_val = 0, is_MIP = 0, view_top = 0, view_bottom = 0;
+    } u_;
+    std::vector<float> cam_block_;           // the "UBO" contents (21 floats)
+    bool cs_program_ = false;                // cs_programID != 0
+
+    int device_ = -1;
+    hipStream_t own_stream_ = nullptr, user_stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    void *d_vol_ = nullptr;
+    size_t vol_alloc_bytes_ = 0;
+    int vol_layout_ = 0;
+    float4 *d_fb_ = nullptr;
+    void *ext_fb_ = nullptr;
+    float4 *d_tf_ = nullptr;
+    uint32_t *d_spp_ = nullptr;
+    size_t spp_capacity_ = 0;
+    unsigned *d_scratch_ = nullptr;          // 2 + 256 words
+    std::vector<float> tf_lut_;              // 256 x RGBA, empty = grey ramp
+    int row_begin_ = 0, row_end_ = -1;
+    int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;
+    bool fb_compact_ = false;
+    std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
+    const char *last_kernel_ = "";
+
+    hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }
+    void requireDevice(const char *what) const;
+    void check(hipError_t e, const char *what) const;
+    void freeVolume();
+    void allocVolume(int nx, int ny, int nz, int bytes, int layout);
+    size_t storageVoxels(int nx, int ny, int nz, int layout) const;
+    void afterVolumeLoaded(const std::string &name);
+    void scanDatasetRange();
+    bool certifyDivisor(float b);
+    void buildFrame(FrameParams &P, LaunchConfig &L);
+    void launch(uint32_t *spp);
+    void setMessage(const std::string &t, const std::string &m) { title = t; msg = m; }
+};
+
+}  // namespace vr

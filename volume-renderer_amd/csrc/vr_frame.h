@@ -1,0 +1,49 @@
+// vr_frame.h -- per-frame constant block shared by the host (renderer_core.cpp) and
+// the gfx950 kernels (vr_kernels.hip).  It is the HIP-side equivalent of the
+// reference's 7 uniforms + 84-byte Camera UBO (VolumeRenderer.cs:28-44) plus the
+// values main() derives from them once per invocation (VolumeRenderer.cs:62-83).
+#pragma once
+#include <stdint.h>
+
+namespace vr {
+
+enum : int { DIV_UNIT = 0, DIV_CERT = 1, DIV_EXACT = 2 };
+
+struct FrameParams {
+    float cam[21];                 // view_mat columns, eye, view_plane_dist
+    int32_t img_w, img_h;          // imageSize(render_texture)
+    int32_t row_begin, row_end;    // global rows rendered by this launch
+    int32_t col_lim, row_lim;      // Q1 limits (== img_w/img_h when the quirk is off)
+    int32_t stripe_rows, stripe_index, stripe_count;  // cyclic row stripes (count 1 = off)
+    int32_t fb_compact;            // 1: target holds only this shard's rows (local row index)
+    int32_t nx, ny, nz;            // textureSize(vol_tex3D)
+    float fdim[3];                 // float(textureSize)
+    float half[3];                 // half_len
+    float pmin[3], pmax[3];        // bb after centring
+    float ext[3];                  // bb.p_max + half_len   (cartesianToTextureCoord)
+    float rext[3];                 // RN(1/ext) for the certified division
+    float step;                    // step_size
+    float alpha_scale;
+    float fmin, fmax, fden;        // vec4(min_val), vec4(max_val), float(max_val-min_val)
+    float rden;                    // RN(1/fden)
+    int32_t min_val, max_val;
+    int32_t view_top, view_bottom;
+    int32_t max_steps;             // 10000
+    int32_t accum;                 // VR_ACCUM_*
+    int32_t tf_len;                // 0 = grey ramp
+    int32_t skip_empty;
+    // bricked layout (VR_LAYOUT_BRICKED): bricks of 4x4x4 voxels, x-fastest inside
+    int32_t bnx, bny, bnz;         // bricks per axis
+};
+
+struct LaunchConfig {
+    int bytes_per_voxel;           // 1 | 2
+    int filter;                    // VR_FILTER_*
+    int mip;                       // 0 | 1
+    int divmode_tc;                // DIV_* for the texcoord division
+    int divmode_win;               // DIV_CERT | DIV_EXACT for the window division
+    int layout;                    // VR_LAYOUT_*
+    int generic;                   // force the generic (always-checked) kernel
+};
+
+}  // namespace vr

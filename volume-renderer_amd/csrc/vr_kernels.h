@@ -1,0 +1,32 @@
+// vr_kernels.h -- host-callable launchers of vr_kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vr_frame.h"
+
+namespace vr {
+
+// true when (P, L) runs on the specialised NEAREST/composite/iterative kernel
+bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L);
+
+// The ray-march launch (replaces glDispatchCompute, src/RendererCore.cpp:150).
+// spp != nullptr selects the instrumented variant that also stores fetch counts.
+hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                           float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name);
+
+// *d_bad must be zeroed by the caller; non-zero afterwards = divisor not certified
+hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st);
+
+hipError_t launch_gen_volume(void *out, int bytes_per_voxel, int kind, uint32_t nx, uint32_t ny, uint32_t nz,
+                             uint32_t param, int layout, uint32_t bnx, uint32_t bny, hipStream_t st);
+
+hipError_t launch_relayout(const void *in, void *out, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz,
+                           uint32_t bnx, uint32_t bny, int to_linear, hipStream_t st);
+
+// pass 0: min/max into d_minmax[2] (init {0xffffffff, 0}); pass 1: 256-bin counts
+hipError_t launch_stats(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
+                        uint32_t bnx, uint32_t bny, int pass, float scale255, unsigned *d_minmax, unsigned *d_hist,
+                        hipStream_t st);
+
+}  // namespace vr

@@ -1,0 +1,643 @@
+// vr_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the ray-march hot path.
+//
+// Replaces the GLSL compute shader /root/reference/VolumeRenderer.cs:55-238 that
+// RendererCore::render() dispatches (/root/reference/src/RendererCore.cpp:138-163).
+// gfx950 has no texture units (tex3D is compile-time unavailable), so the volume is
+// sampled in software from plain HBM allocations.
+//
+// Arithmetic contract (tests/test_parity_gpu.py): every fp32 operation is one
+// correctly rounded IEEE-754 operation in the shader's order; this file is compiled
+// with -ffp-contract=off and hipcc's default correctly rounded fp32 divide/sqrt.
+// The only fused operations are the explicit fmaf() of div_cert(), which is used
+// only for divisors that certify_div_kernel() has proven (exhaustively over all
+// 2^23 significands) to give the correctly rounded quotient.
+//
+// Thread mapping: one pixel per lane, an 8x8 pixel tile per 64-wide wavefront
+// (8 rows x 8 columns: neighbouring rays touch neighbouring voxels), 4 wavefronts
+// (16x16 pixels) per workgroup.  Workgroups are issued in an XCD-aware order (see
+// tile_of_block) so that each XCD's private L2 serves horizontally adjacent tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vr_frame.h"
+#include "vr_kernels.h"
+
+namespace vr {
+
+// ------------------------------------------------------------------ GLSL built-ins
+__device__ __forceinline__ float gl_min(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gl_max(float x, float y) { return (x < y) ? y : x; }
+
+// Markstein quotient: with r = RN(1/b), q0 = RN(a*r), e = a - b*q0 (exact, FMA),
+// q = RN(q0 + e*r).  Correctly rounded for the divisors certify_div_kernel accepted.
+__device__ __forceinline__ float div_cert(float a, float b, float r)
+{
+    float q0 = a * r;
+    float e = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(e, r, q0);
+}
+
+template <int DIVMODE>
+__device__ __forceinline__ float div_mode(float a, float b, float r)
+{
+    if (DIVMODE == DIV_UNIT) return a;          // b == 1.0f exactly
+    if (DIVMODE == DIV_CERT) return div_cert(a, b, r);
+    return a / b;
+}
+
+// Exhaustive proof for one divisor: for every significand a in [1,2) (sign and
+// exponent do not change the rounding pattern in the normal range) the Markstein
+// quotient equals IEEE division.  bad != 0 afterwards means "use DIV_EXACT".
+__global__ void certify_div_kernel(float b, float r, unsigned *bad)
+{
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 2^23 threads
+    float a = __uint_as_float(0x3f800000u | i);
+    float q = div_cert(a, b, r);
+    float ref = a / b;
+    if (__float_as_uint(q) != __float_as_uint(ref)) atomicOr(bad, 1u);
+    // also the scaled-down operand range the texcoord numerator lives in
+    float a2 = a * 0.00390625f;
+    if (__float_as_uint(div_cert(a2, b, r)) != __float_as_uint(a2 / b)) atomicOr(bad, 1u);
+}
+
+// ------------------------------------------------------------------ tile mapping
+// Blocks are numbered so that the hardware's round-robin block->XCD placement
+// (block b runs on XCD b % 8; a speed heuristic only) gives every XCD whole tile
+// rows: tile row = f(b % 8, ...).  Consecutive tile rows go to different XCDs so
+// the empty top/bottom of the image does not idle whole XCDs.
+__device__ __forceinline__ void tile_of_block(unsigned b, unsigned tiles_x, unsigned tiles_y,
+                                              unsigned &tx, unsigned &ty)
+{
+    const unsigned xcd = b & 7u, slot = b >> 3;
+    // XCD x owns tile rows x, x+8, x+16, ...; rows_x = number of those rows
+    const unsigned rows_x = (tiles_y + 7u - xcd) >> 3;
+    const unsigned cap = rows_x * tiles_x;
+    if (slot < cap) {
+        ty = xcd + 8u * (slot / tiles_x);
+        tx = slot % tiles_x;
+    } else {
+        tx = 0xffffffffu; ty = 0xffffffffu;   // padding block
+    }
+}
+
+// ------------------------------------------------------------------ ray setup
+struct Ray { float ox, oy, oz, dx, dy, dz; };
+
+// VolumeRenderer.cs:194-216
+__device__ __forceinline__ Ray compute_ray(const FrameParams &P, float pixel_x, float pixel_y)
+{
+    const float *c = P.cam;
+    const float fw = (float)P.img_w, fh = (float)P.img_h;
+    const float aspect = (fw * 1.0f) / fh;
+    const float x = aspect * (((2.0f * pixel_x) / fw) - 1.0f);
+    const float y = ((2.0f * pixel_y) / fh) - 1.0f;
+    const float z = -c[20];
+    const float w = 0.0f;
+    float len = sqrtf(((x * x + y * y) + z * z) + w * w);
+    const float dx = x / len, dy = y / len, dz = z / len, dw = w / len;
+    const float mx = ((c[0] * dx + c[4] * dy) + c[8] * dz) + c[12] * dw;
+    const float my = ((c[1] * dx + c[5] * dy) + c[9] * dz) + c[13] * dw;
+    const float mz = ((c[2] * dx + c[6] * dy) + c[10] * dz) + c[14] * dw;
+    const float mw = ((c[3] * dx + c[7] * dy) + c[11] * dz) + c[15] * dw;
+    len = sqrtf(((mx * mx + my * my) + mz * mz) + mw * mw);
+    Ray r;
+    r.dx = mx / len; r.dy = my / len; r.dz = mz / len;
+    r.ox = c[16]; r.oy = c[17]; r.oz = c[18];
+    return r;
+}
+
+// VolumeRenderer.cs:218-238
+__device__ __forceinline__ bool intersect_ray_aabb(const FrameParams &P, const Ray &r, float &t_min,
+                                                   float &t_max)
+{
+    float tmax = __builtin_inff(), tmin = -__builtin_inff();
+    const float ix = 1.0f / r.dx, iy = 1.0f / r.dy, iz = 1.0f / r.dz;
+    const float mnx = (P.pmin[0] - r.ox) * ix, mny = (P.pmin[1] - r.oy) * iy, mnz = (P.pmin[2] - r.oz) * iz;
+    const float mxx = (P.pmax[0] - r.ox) * ix, mxy = (P.pmax[1] - r.oy) * iy, mxz = (P.pmax[2] - r.oz) * iz;
+    tmin = gl_max(tmin, gl_min(mnx, mxx));
+    tmax = gl_min(tmax, gl_max(mnx, mxx));
+    tmin = gl_max(tmin, gl_min(mny, mxy));
+    tmax = gl_min(tmax, gl_max(mny, mxy));
+    if (tmax < tmin) return false;
+    tmin = gl_max(tmin, gl_min(mnz, mxz));
+    tmax = gl_min(tmax, gl_max(mnz, mxz));
+    t_min = tmin; t_max = tmax;
+    return tmax > gl_max(tmin, 0.0f);
+}
+
+// ------------------------------------------------------------------ volume access
+template <typename VoxelT, int LAYOUT>
+__device__ __forceinline__ float fetch_voxel(const FrameParams &P, const VoxelT *__restrict__ vol, int i,
+                                             int j, int k)
+{
+    if (LAYOUT == 0) {
+        const uint64_t idx = (uint64_t)(uint32_t)i +
+                             (uint64_t)(uint32_t)P.nx * ((uint64_t)(uint32_t)j + (uint64_t)(uint32_t)P.ny * (uint64_t)(uint32_t)k);
+        return (float)vol[idx];
+    } else {
+        const uint32_t bi = (uint32_t)i >> 2, bj = (uint32_t)j >> 2, bk = (uint32_t)k >> 2;
+        const uint64_t brick = (uint64_t)bi + (uint64_t)(uint32_t)P.bnx * ((uint64_t)bj + (uint64_t)(uint32_t)P.bny * (uint64_t)bk);
+        const uint32_t in = ((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4);
+        return (float)vol[brick * 64u + in];
+    }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// float -> int with the saturation the oracle's (int64) floor + clamp produces
+__device__ __forceinline__ int floor_to_int_sat(float f)
+{
+    f = floorf(f);
+    if (!(f > -2147483648.0f)) return (f != f) ? 0 : -2147483647 - 1;
+    if (f >= 2147483648.0f) return 2147483647;
+    return (int)f;
+}
+
+// ------------------------------------------------------------------ generic kernel
+// One kernel that follows the shader line by line and takes every mode as a run-time
+// (wave-uniform) switch.  It is the correctness backbone: every configuration the
+// specialised kernels do not cover runs here.
+template <typename VoxelT, int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams P, const int filter,
+                                                               const int is_mip, const int divmode,
+                                                               const VoxelT *__restrict__ vol,
+                                                               const float4 *__restrict__ tf,
+                                                               float4 *__restrict__ fb,
+                                                               uint32_t *__restrict__ spp,
+                                                               const unsigned tiles_x, const unsigned tiles_y)
+{
+    unsigned tx, ty;
+    tile_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty);
+    if (tx == 0xffffffffu) return;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lx = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    const int ly = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    // local row -> global row (contiguous shard or cyclic stripes)
+    int px = lx, py;
+    if (P.stripe_count > 1) {
+        const int s = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (s * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    if (px >= P.col_lim || py >= P.row_lim || py >= P.row_end) return;
+
+    const Ray ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+    float t_min = 0.0f, t_max = 0.0f;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+    uint32_t fetches = 0;
+    if (intersect_ray_aabb(P, ray, t_min, t_max)) {
+        const float EPSILON = 0.000001f;
+        const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
+        const float p0x = sx + ray.dx * EPSILON, p0y = sy + ray.dy * EPSILON, p0z = sz + ray.dz * EPSILON;
+        const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+        float qx = p0x, qy = p0y, qz = p0z;
+        for (int i = 0; i < P.max_steps; i++) {
+            if (P.accum == 1) {
+                const float fi = (float)i;
+                qx = p0x + fi * dsx; qy = p0y + fi * dsy; qz = p0z + fi * dsz;
+            }
+            // cartesianToTextureCoord (VolumeRenderer.cs:175-192)
+            float ux = qx + P.half[0], uy = qy + P.half[1], uz = qz + P.half[2];
+            if (divmode == DIV_CERT) {
+                ux = div_cert(ux, P.ext[0], P.rext[0]);
+                uy = div_cert(uy, P.ext[1], P.rext[1]);
+                uz = div_cert(uz, P.ext[2], P.rext[2]);
+            } else {
+                ux = ux / P.ext[0]; uy = uy / P.ext[1]; uz = uz / P.ext[2];
+            }
+            uz = 1.0f - uz;
+            float tcx, tcy, tcz;
+            if (P.view_top == 1) { tcx = ux; tcy = 1.0f - uz; tcz = uy; }
+            else if (P.view_bottom == 1) { tcx = ux; tcy = uz; tcz = 1.0f - uy; }
+            else { tcx = ux; tcy = uy; tcz = uz; }
+            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || d3 >= 0.95f)
+                break;
+            float s;
+            if (filter == 0) {
+                const int vi = clampi(floor_to_int_sat(tcx * P.fdim[0]), 0, P.nx - 1);
+                const int vj = clampi(floor_to_int_sat(tcy * P.fdim[1]), 0, P.ny - 1);
+                const int vk = clampi(floor_to_int_sat(tcz * P.fdim[2]), 0, P.nz - 1);
+                s = fetch_voxel<VoxelT, LAYOUT>(P, vol, vi, vj, vk);
+            } else {
+                const float u = tcx * P.fdim[0] - 0.5f, v = tcy * P.fdim[1] - 0.5f, w = tcz * P.fdim[2] - 0.5f;
+                const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+                const float ax = u - fu, ay = v - fv, az = w - fw;
+                const int iu = (int)fu, iv = (int)fv, iw = (int)fw;
+                const int i0 = clampi(iu, 0, P.nx - 1), i1 = clampi(iu + 1, 0, P.nx - 1);
+                const int j0 = clampi(iv, 0, P.ny - 1), j1 = clampi(iv + 1, 0, P.ny - 1);
+                const int k0 = clampi(iw, 0, P.nz - 1), k1 = clampi(iw + 1, 0, P.nz - 1);
+                const float c000 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i0, j0, k0), c100 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i1, j0, k0);
+                const float c010 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i0, j1, k0), c110 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i1, j1, k0);
+                const float c001 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i0, j0, k1), c101 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i1, j0, k1);
+                const float c011 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i0, j1, k1), c111 = fetch_voxel<VoxelT, LAYOUT>(P, vol, i1, j1, k1);
+                const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+                const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+                const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+                s = c0 + az * (c1 - c0);
+            }
+            fetches++;
+            // window (VolumeRenderer.cs:122-124; Q4: max==min defined as 0)
+            s = gl_min(gl_max(s, P.fmin), P.fmax);
+            if (P.fden == 0.0f) s = 0.0f;
+            else if (s <= P.fmax && s >= P.fmin) s = (s - P.fmin) / P.fden;
+            float s0 = s, s1 = s, s2 = s, s3 = s;
+            if (P.tf_len > 1) {
+                const float fi = s * (float)(P.tf_len - 1) + 0.5f;
+                int idx = floor_to_int_sat(fi);
+                idx = clampi(idx, 0, P.tf_len - 1);
+                const float4 t = tf[idx];
+                s0 = t.x; s1 = t.y; s2 = t.z; s3 = t.w;
+            }
+            if (is_mip == 1) {
+                s0 *= P.alpha_scale; s1 *= P.alpha_scale; s2 *= P.alpha_scale; s3 *= P.alpha_scale;
+                if (d3 < s3) { d0 = s0; d1 = s1; d2 = s2; d3 = s3; }
+            } else {
+                s3 *= P.alpha_scale;
+                s0 *= s3; s1 *= s3; s2 *= s3;
+                const float om = 1.0f - d3;
+                d0 += s0 * om; d1 += s1 * om; d2 += s2 * om; d3 += s3 * om;
+                if (d3 > 0.99f) break;
+            }
+            if (P.accum == 0) { qx += dsx; qy += dsy; qz += dsz; }
+        }
+    }
+    const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+    fb[pix] = make_float4(d0, d1, d2, d3);
+    if (COUNT) spp[pix] = fetches;
+}
+
+// ------------------------------------------------------------------ fast kernel
+// NEAREST + composite + iterative accumulation + grey ramp: the reference's own
+// configuration, and the one BASELINE.json's metric is quoted on.
+//
+// Per ray the samples are split into
+//   * a "safe" prefix of k_safe samples whose texcoords are provably inside (0,1)
+//     (so the shader's six bound tests and the CLAMP_TO_EDGE clamps cannot fire),
+//   * a checked tail that repeats the shader's tests literally.
+// Proof sketch for the prefix (DESIGN.md "safe prefix"): the iterated position
+// pos_k differs from the exact line pos_0 + k*dstep by at most k*2^-24*B, B a bound
+// on |pos|; both are linear in k, so a sample range is safe iff its two end points
+// lie inside the box shrunk by that error plus a fixed 8-ulp margin.
+template <typename VoxelT, int LAYOUT, int DIVTC, int DIVWIN, bool COUNT>
+__global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
+                                                            const VoxelT *__restrict__ vol,
+                                                            float4 *__restrict__ fb,
+                                                            uint32_t *__restrict__ spp,
+                                                            const unsigned tiles_x, const unsigned tiles_y)
+{
+    unsigned tx, ty;
+    tile_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty);
+    if (tx == 0xffffffffu) return;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lx = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
+    const int ly = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    int px = lx, py;
+    if (P.stripe_count > 1) {
+        const int s = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (s * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    if (px >= P.col_lim || py >= P.row_lim || py >= P.row_end) return;
+
+    const Ray ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+    float t_min = 0.0f, t_max = 0.0f;
+    float drgb = 0.0f, da = 0.0f;       // grey ramp: r == g == b bit for bit
+    uint32_t fetches = 0;
+    if (intersect_ray_aabb(P, ray, t_min, t_max)) {
+        const float EPSILON = 0.000001f;
+        const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
+        float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
+        const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+
+        // ---- safe prefix length
+        int k_safe = 0;
+        {
+            // B bounds |pos| for every sample that is still inside the box
+            const float hm = fmaxf(fmaxf(P.half[0], P.half[1]), P.half[2]);
+            const float B = hm + fmaxf(fmaxf(fabsf(dsx), fabsf(dsy)), fabsf(dsz)) + 1e-3f;
+            const float e = B * 1.1920929e-7f;          // 2 * 2^-24 * B per step
+            const float base = hm * 9.5367432e-7f;      // 16 * 2^-24 * hm fixed margin
+            float kmax = (float)P.max_steps;
+            bool ok = true;
+            const float q[3] = { qx, qy, qz }, ds[3] = { dsx, dsy, dsz };
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float lim = P.half[a] - base;     // shrunk half extent
+                // position after k steps must satisfy  q + k*ds + k*e <= lim  and  q + k*ds - k*e >= -lim
+                ok = ok && (q[a] <= lim) && (q[a] >= -lim) && (lim > 0.0f);
+                const float up = ds[a] + e;             // > 0: upper face approached
+                const float dn = ds[a] - e;             // < 0: lower face approached
+                if (up > 0.0f) kmax = fminf(kmax, (lim - q[a]) / up);
+                if (dn < 0.0f) kmax = fminf(kmax, (-lim - q[a]) / dn);
+            }
+            if (ok && kmax > 4.0f) k_safe = (int)(kmax * 0.999f) - 2;
+            if (!(k_safe > 0)) k_safe = 0;
+            if (k_safe > P.max_steps) k_safe = P.max_steps;
+        }
+        const bool swz_top = (P.view_top == 1), swz_bot = (P.view_bottom == 1) && !swz_top;
+        const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
+        int i = 0;
+        bool done = false;
+        // ---- safe prefix: no bound tests, no clamps
+        for (; i < k_safe; i++) {
+            if (da >= 0.95f) { done = true; break; }
+            float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+            float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (swz_top) { tcy = 1.0f - uz; tcz = uy; }
+            else if (swz_bot) { tcy = uz; tcz = 1.0f - uy; }
+            const int vi = (int)(tcx * P.fdim[0]);
+            const int vj = (int)(tcy * P.fdim[1]);
+            const int vk = (int)(tcz * P.fdim[2]);
+            float s = fetch_voxel<VoxelT, LAYOUT>(P, vol, vi, vj, vk);
+            s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
+            s = div_mode<DIVWIN>(s - P.fmin, P.fden, P.rden);
+            const float a = s * P.alpha_scale;
+            const float c = s * a;
+            const float om = 1.0f - da;
+            drgb += c * om;
+            da += a * om;
+            if (da > 0.99f) { i++; done = true; break; }
+            qx += dsx; qy += dsy; qz += dsz;
+        }
+        // ---- checked tail: the shader's loop, literally
+        if (!done) {
+            for (; i < P.max_steps; i++) {
+                float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+                float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+                float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+                uz = 1.0f - uz;
+                float tcx = ux, tcy = uy, tcz = uz;
+                if (swz_top) { tcy = 1.0f - uz; tcz = uy; }
+                else if (swz_bot) { tcy = uz; tcz = 1.0f - uy; }
+                if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f)
+                    break;
+                const int vi = min((int)(tcx * P.fdim[0]), nxm1);
+                const int vj = min((int)(tcy * P.fdim[1]), nym1);
+                const int vk = min((int)(tcz * P.fdim[2]), nzm1);
+                float s = fetch_voxel<VoxelT, LAYOUT>(P, vol, vi, vj, vk);
+                s = fminf(fmaxf(s, P.fmin), P.fmax);
+                s = div_mode<DIVWIN>(s - P.fmin, P.fden, P.rden);
+                const float a = s * P.alpha_scale;
+                const float c = s * a;
+                const float om = 1.0f - da;
+                drgb += c * om;
+                da += a * om;
+                if (da > 0.99f) { i++; break; }
+                qx += dsx; qy += dsy; qz += dsz;
+            }
+        }
+        fetches = (uint32_t)i;
+    }
+    const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+    fb[pix] = make_float4(drgb, drgb, drgb, da);
+    if (COUNT) spp[pix] = fetches;
+}
+
+// ------------------------------------------------------------------ helper kernels
+__device__ __forceinline__ uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+
+__device__ __forceinline__ uint32_t isqrt_u64(uint64_t v)
+{
+    uint64_t r = (uint64_t)sqrt((double)v);
+    while (r * r > v) r--;
+    while ((r + 1) * (r + 1) <= v) r++;
+    return (uint32_t)r;
+}
+
+// linear voxel index -> storage index (identity for VR_LAYOUT_LINEAR)
+__device__ __forceinline__ uint64_t storage_index(int layout, uint32_t i, uint32_t j, uint32_t k, uint32_t nx,
+                                                  uint32_t ny, uint32_t bnx, uint32_t bny)
+{
+    if (layout == 0) return (uint64_t)i + (uint64_t)nx * ((uint64_t)j + (uint64_t)ny * (uint64_t)k);
+    const uint64_t brick = (uint64_t)(i >> 2) + (uint64_t)bnx * ((uint64_t)(j >> 2) + (uint64_t)bny * (uint64_t)(k >> 2));
+    return brick * 64u + ((i & 3u) | ((j & 3u) << 2) | ((k & 3u) << 4));
+}
+
+template <typename VoxelT>
+__global__ __launch_bounds__(256) void gen_volume_kernel(VoxelT *__restrict__ out, int kind, uint32_t nx,
+                                                         uint32_t ny, uint32_t nz, uint32_t param, int layout,
+                                                         uint32_t bnx, uint32_t bny)
+{
+    const uint64_t total = (uint64_t)nx * ny * nz;
+    for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+         lin += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(lin % nx), j = (uint32_t)((lin / nx) % ny), k = (uint32_t)(lin / ((uint64_t)nx * ny));
+        const int64_t a = 2 * (int64_t)i + 1 - (int64_t)nx, b = 2 * (int64_t)j + 1 - (int64_t)ny,
+                      c = 2 * (int64_t)k + 1 - (int64_t)nz;
+        const int64_t r2 = a * a + b * b + c * c;
+        int64_t v;
+        if (kind == 0) {   // VR_SYNTH_SPHERE_U8: param = radius
+            const int64_t twoR = 2 * (int64_t)param;
+            v = r2 < twoR * twoR ? 255 - (255 * (int64_t)isqrt_u64((uint64_t)r2)) / twoR : 0;
+        } else {           // VR_SYNTH_NOISE_BALL: param = seed
+            int64_t N = nx > ny ? nx : ny; N = N > (int64_t)nz ? N : (int64_t)nz;
+            const int64_t vmax = sizeof(VoxelT) == 2 ? 4095 : 255;
+            const int shift = sizeof(VoxelT) == 2 ? 2 : 6;
+            const int64_t n2 = N * N;
+            const int64_t base = r2 < n2 ? (vmax * (n2 - r2)) / n2 : 0;
+            const uint32_t h = fmix32(((uint32_t)lin ^ (uint32_t)(lin >> 32) * 0x9E3779B1u) ^ param) & 0xFFu;
+            v = base + (int64_t)(h >> shift);
+            if (v > vmax) v = vmax;
+        }
+        out[storage_index(layout, i, j, k, nx, ny, bnx, bny)] = (VoxelT)v;
+    }
+}
+
+// re-layout between linear and bricked storage (dir 0: linear -> bricked, 1: back)
+template <typename VoxelT>
+__global__ __launch_bounds__(256) void relayout_kernel(const VoxelT *__restrict__ in, VoxelT *__restrict__ out,
+                                                       uint32_t nx, uint32_t ny, uint32_t nz, uint32_t bnx,
+                                                       uint32_t bny, int to_linear)
+{
+    const uint64_t total = (uint64_t)nx * ny * nz;
+    for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+         lin += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(lin % nx), j = (uint32_t)((lin / nx) % ny), k = (uint32_t)(lin / ((uint64_t)nx * ny));
+        const uint64_t b = storage_index(1, i, j, k, nx, ny, bnx, bny);
+        if (to_linear) out[lin] = in[b];
+        else out[b] = in[lin];
+    }
+}
+
+// dataset min/max scan (src/RendererCore.cpp:362-379, including the skipped index
+// 8390640) and the raw 256-bin counts of :386-399
+template <typename VoxelT>
+__global__ __launch_bounds__(256) void stats_kernel(const VoxelT *__restrict__ vol, uint32_t nx, uint32_t ny,
+                                                    uint32_t nz, int layout, uint32_t bnx, uint32_t bny,
+                                                    int pass, float scale255, unsigned *minmax, unsigned *hist)
+{
+    __shared__ unsigned lh[256];
+    __shared__ unsigned lmin, lmax;
+    if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { lmin = 0xffffffffu; lmax = 0; }
+    __syncthreads();
+    const uint64_t total = (uint64_t)nx * ny * nz;
+    unsigned mn = 0xffffffffu, mx = 0;
+    for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
+         lin += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(lin % nx), j = (uint32_t)((lin / nx) % ny), k = (uint32_t)(lin / ((uint64_t)nx * ny));
+        const unsigned v = vol[storage_index(layout, i, j, k, nx, ny, bnx, bny)];
+        if (pass == 0) {
+            if (lin == 8390640ull) continue;
+            mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        } else {
+            unsigned bin = v;
+            if (sizeof(VoxelT) == 2) {
+                // val = std::round(val * 255.0f / max_dataset_val) stored to uint16_t
+                const float f = roundf(((float)v * 255.0f) / scale255);
+                bin = (unsigned)f & 0xffffu;
+            }
+            if (bin != 0 && bin < 256) atomicAdd(&lh[bin], 1u);
+        }
+    }
+    if (pass == 0) {
+        atomicMin(&lmin, mn); atomicMax(&lmax, mx);
+        __syncthreads();
+        if (threadIdx.x == 0) { atomicMin(&minmax[0], lmin); atomicMax(&minmax[1], lmax); }
+    } else {
+        __syncthreads();
+        if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+static inline unsigned padded_blocks(unsigned tiles_x, unsigned tiles_y)
+{
+    // every XCD gets ceil(tiles_y/8) tile rows' worth of slots; extras are padding
+    const unsigned rows0 = (tiles_y + 7u) / 8u;
+    return rows0 * tiles_x * 8u;
+}
+
+template <typename VoxelT, int LAYOUT, bool COUNT>
+static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                                 float4 *fb, uint32_t *spp, unsigned tiles_x, unsigned tiles_y, hipStream_t st)
+{
+    const int div = L.divmode_tc == DIV_EXACT ? DIV_EXACT : DIV_CERT;
+    hipLaunchKernelGGL((raymarch_generic_kernel<VoxelT, LAYOUT, COUNT>), dim3(padded_blocks(tiles_x, tiles_y)),
+                       dim3(256), 0, st, P, L.filter, L.mip, div, (const VoxelT *)vol, tf, fb, spp, tiles_x,
+                       tiles_y);
+    return hipGetLastError();
+}
+
+template <typename VoxelT, int LAYOUT, int DIVTC, int DIVWIN, bool COUNT>
+static hipError_t launch_fast(const FrameParams &P, const void *vol, float4 *fb, uint32_t *spp, unsigned tiles_x,
+                              unsigned tiles_y, hipStream_t st)
+{
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, DIVWIN, COUNT>),
+                       dim3(padded_blocks(tiles_x, tiles_y)), dim3(256), 0, st, P, (const VoxelT *)vol, fb, spp,
+                       tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+template <typename VoxelT, int LAYOUT, bool COUNT>
+static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
+                                uint32_t *spp, unsigned tx, unsigned ty, hipStream_t st)
+{
+#define VR_CASE(TC, WIN)                                                                  \
+    if (L.divmode_tc == TC && L.divmode_win == WIN)                                       \
+        return launch_fast<VoxelT, LAYOUT, TC, WIN, COUNT>(P, vol, fb, spp, tx, ty, st);
+    VR_CASE(DIV_UNIT, DIV_CERT)
+    VR_CASE(DIV_UNIT, DIV_EXACT)
+    VR_CASE(DIV_CERT, DIV_CERT)
+    VR_CASE(DIV_CERT, DIV_EXACT)
+    VR_CASE(DIV_EXACT, DIV_CERT)
+    VR_CASE(DIV_EXACT, DIV_EXACT)
+#undef VR_CASE
+    return hipErrorInvalidValue;
+}
+
+bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
+{
+    return !L.generic && L.filter == 0 && L.mip == 0 && P.accum == 0 && P.tf_len <= 1 && P.fden > 0.0f &&
+           P.max_val > P.min_val;
+}
+
+hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                           float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name)
+{
+    // local image rows covered by this launch
+    int rows;
+    if (P.stripe_count > 1) {
+        const int nstripes_total = (P.img_h + P.stripe_rows - 1) / P.stripe_rows;
+        const int mine = (nstripes_total - P.stripe_index + P.stripe_count - 1) / P.stripe_count;
+        rows = mine * P.stripe_rows;
+    } else {
+        rows = P.row_end - P.row_begin;
+    }
+    if (rows <= 0 || P.img_w <= 0) return hipSuccess;
+    const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
+    const bool count = spp != nullptr;
+    const bool fast = fast_path_eligible(P, L);
+    if (kernel_name) *kernel_name = fast ? "raymarch_fast_kernel" : "raymarch_generic_kernel";
+#define VR_GO(T, LAY)                                                                                        \
+    do {                                                                                                      \
+        if (fast)                                                                                             \
+            return count ? dispatch_fast<T, LAY, true>(P, L, vol, fb, spp, tiles_x, tiles_y, st)              \
+                         : dispatch_fast<T, LAY, false>(P, L, vol, fb, spp, tiles_x, tiles_y, st);            \
+        return count ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)             \
+                     : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);           \
+    } while (0)
+    if (L.bytes_per_voxel == 1) {
+        if (L.layout == 0) VR_GO(uint8_t, 0); else VR_GO(uint8_t, 1);
+    } else {
+        if (L.layout == 0) VR_GO(uint16_t, 0); else VR_GO(uint16_t, 1);
+    }
+#undef VR_GO
+}
+
+hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(certify_div_kernel, dim3((1u << 23) / 256u), dim3(256), 0, st, b, r, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_volume(void *out, int bytes_per_voxel, int kind, uint32_t nx, uint32_t ny, uint32_t nz,
+                             uint32_t param, int layout, uint32_t bnx, uint32_t bny, hipStream_t st)
+{
+    const unsigned blocks = 256 * 16;
+    if (bytes_per_voxel == 1)
+        hipLaunchKernelGGL(gen_volume_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (uint8_t *)out, kind, nx, ny,
+                           nz, param, layout, bnx, bny);
+    else
+        hipLaunchKernelGGL(gen_volume_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (uint16_t *)out, kind, nx,
+                           ny, nz, param, layout, bnx, bny);
+    return hipGetLastError();
+}
+
+hipError_t launch_relayout(const void *in, void *out, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz,
+                           uint32_t bnx, uint32_t bny, int to_linear, hipStream_t st)
+{
+    const unsigned blocks = 256 * 16;
+    if (bytes_per_voxel == 1)
+        hipLaunchKernelGGL(relayout_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t *)in,
+                           (uint8_t *)out, nx, ny, nz, bnx, bny, to_linear);
+    else
+        hipLaunchKernelGGL(relayout_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)in,
+                           (uint16_t *)out, nx, ny, nz, bnx, bny, to_linear);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
+                        uint32_t bnx, uint32_t bny, int pass, float scale255, unsigned *d_minmax, unsigned *d_hist,
+                        hipStream_t st)
+{
+    const unsigned blocks = 256 * 8;
+    if (bytes_per_voxel == 1)
+        hipLaunchKernelGGL(stats_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t *)vol, nx, ny, nz,
+                           layout, bnx, bny, pass, scale255, d_minmax, d_hist);
+    else
+        hipLaunchKernelGGL(stats_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)vol, nx, ny,
+                           nz, layout, bnx, bny, pass, scale255, d_minmax, d_hist);
+    return hipGetLastError();
+}
+
+}  // namespace vr
