@@ -101,7 +101,10 @@ def main():
 
     plan = sharding.plan_rows(H, world, rank, args.partition, args.stripe_rows)
     sharding.apply_plan(r, plan)
-    stream = torch.cuda.current_stream(dev)
+    # a dedicated (non-null) torch stream: the kernel, the HIP events and RCCL all use it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     r.setStream(stream.cuda_stream)
     local = torch.zeros((plan.local_rows, W, 4), dtype=torch.float32, device=dev)
     r.setFramebufferExternal(local.data_ptr())
