@@ -527,6 +527,18 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic;
+    // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
+    {
+        const uint64_t bsy = 64ull * (uint64_t)P.bnx - 16ull, bsz = 64ull * (uint64_t)P.bnx * (uint64_t)P.bny - 64ull;
+        P.bstride_y = (uint32_t)bsy;
+        P.bstride_z = (uint32_t)bsz;
+        const uint64_t storage = storageVoxels(nx, ny, nz, vol_layout_);
+        const uint64_t lim24 = 1ull << 24;
+        bool small = storage < (1ull << 32) && (uint64_t)nx < lim24 && (uint64_t)ny < lim24 && (uint64_t)nz < lim24;
+        if (vol_layout_ == 0) small = small && (uint64_t)ny * (uint64_t)nz < lim24;
+        else small = small && bsy < lim24 && bsz < lim24;
+        L.big_offsets = small ? 0 : 1;
+    }
     // division strategy: unit extents need no division at all; other divisors use the
     // 3-op Markstein quotient only after an exhaustive on-device certification
     const bool unit = P.ext[0] == 1.0f && P.ext[1] == 1.0f && P.ext[2] == 1.0f;

@@ -34,6 +34,7 @@ struct FrameParams {
     int32_t skip_empty;
     // bricked layout (VR_LAYOUT_BRICKED): bricks of 4x4x4 voxels, x-fastest inside
     int32_t bnx, bny, bnz;         // bricks per axis
+    uint32_t bstride_y, bstride_z; // 64*bnx - 16 and 64*bnx*bny - 64 (see VoxelAddr)
 };
 
 struct LaunchConfig {
@@ -44,6 +45,7 @@ struct LaunchConfig {
     int divmode_win;               // DIV_CERT | DIV_EXACT for the window division
     int layout;                    // VR_LAYOUT_*
     int generic;                   // force the generic (always-checked) kernel
+    int big_offsets;               // voxel offsets need 64-bit arithmetic
 };
 
 }  // namespace vr

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vr_frame.h"
 #include "vr_kernels.h"
 
@@ -278,8 +280,43 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 // Proof sketch for the prefix (DESIGN.md "safe prefix"): the iterated position
 // pos_k differs from the exact line pos_0 + k*dstep by at most k*2^-24*B, B a bound
 // on |pos|; both are linear in k, so a sample range is safe iff its two end points
-// lie inside the box shrunk by that error plus a fixed 8-ulp margin.
-template <typename VoxelT, int LAYOUT, int DIVTC, int DIVWIN, bool COUNT>
+// lie inside the box shrunk by that error plus a fixed 16-ulp margin.
+//
+// The prefix is marched in batches of FAST_BATCH samples: positions do not depend on
+// the voxel data, so the batch's FAST_BATCH gathers are issued back to back (memory-
+// level parallelism: the loop is latency-bound otherwise) and composited in order
+// afterwards, with the shader's early-termination tests between samples.  Gathers
+// past an early termination are speculative reads inside the volume; they change
+// neither the result nor the reported fetch count.
+constexpr int FAST_BATCH = 8;
+
+// byte-free voxel offset of (i,j,k).  BIG = false: 32-bit arithmetic with 24-bit
+// multiplies (host guarantees ny*nz < 2^24 and storage voxels < 2^32).
+template <int LAYOUT, bool BIG>
+struct VoxelAddr {
+    using type = typename std::conditional<BIG, uint64_t, uint32_t>::type;
+    __device__ static __forceinline__ type at(const FrameParams &P, int i, int j, int k)
+    {
+        if (LAYOUT == 0) {
+            if (BIG)
+                return (type)((uint64_t)(uint32_t)i + (uint64_t)(uint32_t)P.nx * ((uint64_t)(uint32_t)j + (uint64_t)(uint32_t)P.ny * (uint64_t)(uint32_t)k));
+            const uint32_t row = __umul24((uint32_t)k, (uint32_t)P.ny) + (uint32_t)j;
+            return (type)(__umul24(row, (uint32_t)P.nx) + (uint32_t)i);
+        } else {
+            // f(i) = (i&3) + (i>>2)*64 = i + (i>>2)*60, and likewise for j (x4) and k (x16)
+            if (BIG) {
+                const uint64_t brick = (uint64_t)((uint32_t)i >> 2) + (uint64_t)(uint32_t)P.bnx * ((uint64_t)((uint32_t)j >> 2) + (uint64_t)(uint32_t)P.bny * (uint64_t)((uint32_t)k >> 2));
+                return (type)(brick * 64u + (((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4)));
+            }
+            const uint32_t fi = __umul24((uint32_t)i >> 2, 60u) + (uint32_t)i;
+            const uint32_t fj = __umul24((uint32_t)j >> 2, (uint32_t)P.bstride_y) + ((uint32_t)j << 2);
+            const uint32_t fk = __umul24((uint32_t)k >> 2, (uint32_t)P.bstride_z) + ((uint32_t)k << 4);
+            return (type)(fi + fj + fk);
+        }
+    }
+};
+
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG>
 __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             float4 *__restrict__ fb,
@@ -336,57 +373,77 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
             if (!(k_safe > 0)) k_safe = 0;
             if (k_safe > P.max_steps) k_safe = P.max_steps;
         }
-        const bool swz_top = (P.view_top == 1), swz_bot = (P.view_bottom == 1) && !swz_top;
-        const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
-        int i = 0;
-        bool done = false;
-        // ---- safe prefix: no bound tests, no clamps
-        for (; i < k_safe; i++) {
-            if (da >= 0.95f) { done = true; break; }
-            float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-            float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+
+        // texcoord -> voxel index of the position (qx,qy,qz); valid (unclamped) inside the prefix
+        auto voxel_of = [&](float ax, float ay, float az, int &vi, int &vj, int &vk) {
+            const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);
             uz = 1.0f - uz;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (swz_top) { tcy = 1.0f - uz; tcz = uy; }
-            else if (swz_bot) { tcy = uz; tcz = 1.0f - uy; }
-            const int vi = (int)(tcx * P.fdim[0]);
-            const int vj = (int)(tcy * P.fdim[1]);
-            const int vk = (int)(tcz * P.fdim[2]);
-            float s = fetch_voxel<VoxelT, LAYOUT>(P, vol, vi, vj, vk);
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }          // view_top
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }     // view_bottom
+            vi = (int)(tcx * P.fdim[0]);
+            vj = (int)(tcy * P.fdim[1]);
+            vk = (int)(tcz * P.fdim[2]);
+        };
+        // window + grey-ramp classification + front-to-back compositing of one sample
+        auto composite = [&](float s) {
             s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
-            s = div_mode<DIVWIN>(s - P.fmin, P.fden, P.rden);
+            s = div_cert(s - P.fmin, P.fden, P.rden);
             const float a = s * P.alpha_scale;
             const float c = s * a;
             const float om = 1.0f - da;
             drgb += c * om;
             da += a * om;
-            if (da > 0.99f) { i++; done = true; break; }
-            qx += dsx; qy += dsy; qz += dsz;
+        };
+
+        int i = 0;
+        bool done = false;
+        // ---- safe prefix, FAST_BATCH samples per trip
+        const int n_batched = k_safe - (k_safe % FAST_BATCH);
+        while (i < n_batched) {
+            typename VoxelAddr<LAYOUT, BIG>::type off[FAST_BATCH];
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) {
+                int vi, vj, vk;
+                voxel_of(qx, qy, qz, vi, vj, vk);
+                off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
+                qx += dsx; qy += dsy; qz += dsz;
+            }
+            float v[FAST_BATCH];
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) v[u] = (float)vol[off[u]];
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) {
+                if (!done) {
+                    if (da >= 0.95f) { done = true; }
+                    else {
+                        composite(v[u]);
+                        i++;
+                        if (da > 0.99f) done = true;
+                    }
+                }
+            }
+            if (done) break;
         }
         // ---- checked tail: the shader's loop, literally
         if (!done) {
+            const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
             for (; i < P.max_steps; i++) {
-                float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-                float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+                const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+                const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
                 float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
                 uz = 1.0f - uz;
                 float tcx = ux, tcy = uy, tcz = uz;
-                if (swz_top) { tcy = 1.0f - uz; tcz = uy; }
-                else if (swz_bot) { tcy = uz; tcz = 1.0f - uy; }
+                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
                 if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f)
                     break;
                 const int vi = min((int)(tcx * P.fdim[0]), nxm1);
                 const int vj = min((int)(tcy * P.fdim[1]), nym1);
                 const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-                float s = fetch_voxel<VoxelT, LAYOUT>(P, vol, vi, vj, vk);
-                s = fminf(fmaxf(s, P.fmin), P.fmax);
-                s = div_mode<DIVWIN>(s - P.fmin, P.fden, P.rden);
-                const float a = s * P.alpha_scale;
-                const float c = s * a;
-                const float om = 1.0f - da;
-                drgb += c * om;
-                da += a * om;
+                composite((float)vol[VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)]);
                 if (da > 0.99f) { i++; break; }
                 qx += dsx; qy += dsy; qz += dsz;
             }
@@ -395,7 +452,7 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
     }
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
     fb[pix] = make_float4(drgb, drgb, drgb, da);
-    if (COUNT) spp[pix] = fetches;
+    if (spp) spp[pix] = fetches;
 }
 
 // ------------------------------------------------------------------ helper kernels
@@ -528,37 +585,39 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int DIVWIN, bool COUNT>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG>
 static hipError_t launch_fast(const FrameParams &P, const void *vol, float4 *fb, uint32_t *spp, unsigned tiles_x,
                               unsigned tiles_y, hipStream_t st)
 {
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, DIVWIN, COUNT>),
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG>),
                        dim3(padded_blocks(tiles_x, tiles_y)), dim3(256), 0, st, P, (const VoxelT *)vol, fb, spp,
                        tiles_x, tiles_y);
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, bool COUNT>
+template <typename VoxelT, int LAYOUT>
 static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
                                 uint32_t *spp, unsigned tx, unsigned ty, hipStream_t st)
 {
-#define VR_CASE(TC, WIN)                                                                  \
-    if (L.divmode_tc == TC && L.divmode_win == WIN)                                       \
-        return launch_fast<VoxelT, LAYOUT, TC, WIN, COUNT>(P, vol, fb, spp, tx, ty, st);
-    VR_CASE(DIV_UNIT, DIV_CERT)
-    VR_CASE(DIV_UNIT, DIV_EXACT)
-    VR_CASE(DIV_CERT, DIV_CERT)
-    VR_CASE(DIV_CERT, DIV_EXACT)
-    VR_CASE(DIV_EXACT, DIV_CERT)
-    VR_CASE(DIV_EXACT, DIV_EXACT)
+    const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
+    const bool big = L.big_offsets != 0;
+#define VR_CASE(TC, VW, BG)                                                               \
+    if (L.divmode_tc == TC && view == VW && big == BG)                                    \
+        return launch_fast<VoxelT, LAYOUT, TC, VW, BG>(P, vol, fb, spp, tx, ty, st);
+    VR_CASE(DIV_UNIT, 0, false) VR_CASE(DIV_UNIT, 1, false) VR_CASE(DIV_UNIT, 2, false)
+    VR_CASE(DIV_CERT, 0, false) VR_CASE(DIV_CERT, 1, false) VR_CASE(DIV_CERT, 2, false)
+    VR_CASE(DIV_UNIT, 0, true) VR_CASE(DIV_UNIT, 1, true) VR_CASE(DIV_UNIT, 2, true)
+    VR_CASE(DIV_CERT, 0, true) VR_CASE(DIV_CERT, 1, true) VR_CASE(DIV_CERT, 2, true)
 #undef VR_CASE
     return hipErrorInvalidValue;
 }
 
+// The specialised kernel covers NEAREST / composite / iterative / grey ramp with a
+// non-degenerate window whose divisions were certified; everything else is generic.
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
 {
     return !L.generic && L.filter == 0 && L.mip == 0 && P.accum == 0 && P.tf_len <= 1 && P.fden > 0.0f &&
-           P.max_val > P.min_val;
+           P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT;
 }
 
 hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
@@ -580,9 +639,7 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     if (kernel_name) *kernel_name = fast ? "raymarch_fast_kernel" : "raymarch_generic_kernel";
 #define VR_GO(T, LAY)                                                                                        \
     do {                                                                                                      \
-        if (fast)                                                                                             \
-            return count ? dispatch_fast<T, LAY, true>(P, L, vol, fb, spp, tiles_x, tiles_y, st)              \
-                         : dispatch_fast<T, LAY, false>(P, L, vol, fb, spp, tiles_x, tiles_y, st);            \
+        if (fast) return dispatch_fast<T, LAY>(P, L, vol, fb, spp, tiles_x, tiles_y, st);                     \
         return count ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)             \
                      : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);           \
     } while (0)
