@@ -11,6 +11,7 @@
 #include <fstream>
 #include <iostream>
 
+#include "tile_schedule.h"
 #include "volume_io.h"
 #include "vr_kernels.h"
 
@@ -44,6 +45,7 @@ RendererCore::~RendererCore()
         freeVolume();
         if (d_fb_) (void)hipFree(d_fb_);
         if (d_tf_) (void)hipFree(d_tf_);
+        if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (ev0_) (void)hipEventDestroy(ev0_);
@@ -468,6 +470,7 @@ bool RendererCore::certifyDivisor(float b)
 void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
 {
     std::memset(&P, 0, sizeof(P));
+    std::memset(&L, 0, sizeof(L));
     if (cam_block_.size() != 21 || main_cam.is_changed) setupUBO(true);
     std::memcpy(P.cam, cam_block_.data(), sizeof(float) * 21);
     P.img_w = framebuffer_size[0];
@@ -537,7 +540,12 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         bool small = storage < (1ull << 32) && (uint64_t)nx < lim24 && (uint64_t)ny < lim24 && (uint64_t)nz < lim24;
         if (vol_layout_ == 0) small = small && (uint64_t)ny * (uint64_t)nz < lim24;
         else small = small && bsy < lim24 && bsz < lim24;
+        const uint64_t bytes = storage * (uint64_t)datasize_bytes;
+        if (bytes >= (1ull << 32)) small = false;
         L.big_offsets = small ? 0 : 1;
+        L.vol_bytes32 = small ? (uint32_t)bytes : 0u;
+        const int64_t width = (int64_t)u_.max_val - (int64_t)u_.min_val + 1;
+        L.use_lut = (width >= 2 && width <= 4096) ? 1 : 0;
     }
     // division strategy: unit extents need no division at all; other divisors use the
     // 3-op Markstein quotient only after an exhaustive on-device certification
@@ -557,7 +565,36 @@ void RendererCore::launch(uint32_t *spp)
     FrameParams P;
     LaunchConfig L;
     buildFrame(P, L);
+    refreshTileSchedule(P, L);
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
+}
+
+// Rebuild the longest-first block order when the camera / image / shard changed.  The
+// table is tiny (one word per 32x16-pixel tile) and is uploaded on the launch stream.
+void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
+{
+    L.tile_table = nullptr;
+    L.tile_table_blocks = 0;
+    if (!tile_order || !fast_path_eligible(P, L)) return;
+    const int rows = launch_local_rows(P);
+    if (rows <= 0) return;
+    const uint64_t key = tileScheduleKey(P, rows);
+    if (key != tile_table_key_ || !d_tile_table_) {
+        std::vector<uint32_t> table;
+        buildTileSchedule(P, rows, table);
+        if (table.size() > tile_table_capacity_) {
+            if (d_tile_table_) { check(hipFree(d_tile_table_), "hipFree(tile table)"); d_tile_table_ = nullptr; }
+            check(hipMalloc(reinterpret_cast<void **>(&d_tile_table_), table.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
+            tile_table_capacity_ = table.size();
+        }
+        // synchronous copy: `table` is a pageable temporary
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        check(hipMemcpy(d_tile_table_, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
+        tile_table_blocks_ = table.size();
+        tile_table_key_ = key;
+    }
+    L.tile_table = d_tile_table_;
+    L.tile_table_blocks = (uint32_t)tile_table_blocks_;
 }
 
 void RendererCore::render()
@@ -567,7 +604,7 @@ void RendererCore::render()
     // on its result (src/RendererCore.cpp:149-153); same shape with HIP events
     FrameParams P;   // certify (may sync) before the timed region
     LaunchConfig L;
-    if (cs_program_ && d_vol_) buildFrame(P, L);
+    if (cs_program_ && d_vol_) { buildFrame(P, L); refreshTileSchedule(P, L); }
     check(hipEventRecord(ev0_, stream()), "hipEventRecord");
     launch(nullptr);
     check(hipEventRecord(ev1_, stream()), "hipEventRecord");

@@ -89,6 +89,7 @@ public:
     int filter = 0, accum = 0, layout = 0, skip_empty = 0;
     uint32_t quirks = 2u;   // VR_QUIRK_DEFAULT
     int force_generic = 0;
+    int tile_order = 1;      // 1: longest-first tile schedule, 0: arithmetic order
     std::string last_error;
 
 private:
@@ -118,6 +119,10 @@ private:
     int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;
     bool fb_compact_ = false;
     std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
+    uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
+    size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
+    uint64_t tile_table_key_ = 0;
+    void refreshTileSchedule(const FrameParams &P, LaunchConfig &L);
     const char *last_kernel_ = "";
 
     hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }

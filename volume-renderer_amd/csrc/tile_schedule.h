@@ -1,0 +1,27 @@
+// tile_schedule.h -- work-ordered, XCD-balanced block -> tile table for the fast kernel.
+//
+// Rays that cross the whole volume take ~4x longer than rays clipping a corner, and one
+// frame is only ~1.3 "rounds" of resident wavefronts, so dispatch order decides the tail:
+// blocks are issued longest-first (LPT), dealt round-robin to the 8 XCDs in chunks of
+// horizontally adjacent tiles (shared cache lines stay on one XCD's L2).  A scheduling
+// heuristic only: pixels are independent, the image does not depend on it.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "vr_frame.h"
+
+namespace vr {
+
+constexpr unsigned kFastTileW = 32, kFastTileH = 16, kFastChunk = 4;
+constexpr uint32_t kTilePadding = 0xffffffffu;
+
+// table[b] = tile_x | tile_y << 16 for block b, kTilePadding for padding blocks.
+// `rows` = local image rows of this launch (stripe padding included).
+void buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table);
+
+// cheap fingerprint of everything the schedule depends on
+uint64_t tileScheduleKey(const FrameParams &P, int rows);
+
+}  // namespace vr

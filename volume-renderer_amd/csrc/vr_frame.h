@@ -46,6 +46,10 @@ struct LaunchConfig {
     int layout;                    // VR_LAYOUT_*
     int generic;                   // force the generic (always-checked) kernel
     int big_offsets;               // voxel offsets need 64-bit arithmetic
+    int use_lut;                   // LDS classification table (window width <= 4096 entries)
+    uint32_t vol_bytes32;          // volume allocation size for the buffer descriptor (!big)
+    const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
+    uint32_t tile_table_blocks;
 };
 
 }  // namespace vr

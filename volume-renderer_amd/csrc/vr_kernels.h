@@ -10,6 +10,9 @@ namespace vr {
 // true when (P, L) runs on the specialised NEAREST/composite/iterative kernel
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L);
 
+// local image rows one launch covers (stripe padding included)
+int launch_local_rows(const FrameParams &P);
+
 // The ray-march launch (replaces glDispatchCompute, src/RendererCore.cpp:150).
 // spp != nullptr selects the instrumented variant that also stores fetch counts.
 hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "vr_frame.h"
+#include "tile_schedule.h"
 #include "vr_kernels.h"
 
 namespace vr {
@@ -288,10 +289,27 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 // afterwards, with the shader's early-termination tests between samples.  Gathers
 // past an early termination are speculative reads inside the volume; they change
 // neither the result nor the reported fetch count.
-constexpr int FAST_BATCH = 8;
+//
+// Classification table (LUT = true): the window map + alpha scaling of a sample is a
+// pure function of the integer voxel value, so each workgroup first tabulates
+//   e -> (c, a) = (v*a, v*alpha_scale),  v = (float(min_val+e) - min_val)/(max_val-min_val)
+// for e in [0, max_val-min_val] in LDS with the shader's own operations (so entries are
+// bit-identical to the per-sample computation) and a sample then costs one ds_read_b64.
+#ifndef VR_FAST_BATCH
+#define VR_FAST_BATCH 8
+#endif
+constexpr int FAST_BATCH = VR_FAST_BATCH;
+constexpr int FAST_LUT_MAX = 4096;      // entries (x 8 B = 32 KiB of the CU's 160 KiB LDS)
 
-// byte-free voxel offset of (i,j,k).  BIG = false: 32-bit arithmetic with 24-bit
-// multiplies (host guarantees ny*nz < 2^24 and storage voxels < 2^32).
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// element offset of voxel (i,j,k).  BIG = false: 32-bit arithmetic with 24-bit
+// multiplies (host guarantees every factor < 2^24 and storage voxels < 2^32).
 template <int LAYOUT, bool BIG>
 struct VoxelAddr {
     using type = typename std::conditional<BIG, uint64_t, uint32_t>::type;
@@ -300,35 +318,90 @@ struct VoxelAddr {
         if (LAYOUT == 0) {
             if (BIG)
                 return (type)((uint64_t)(uint32_t)i + (uint64_t)(uint32_t)P.nx * ((uint64_t)(uint32_t)j + (uint64_t)(uint32_t)P.ny * (uint64_t)(uint32_t)k));
-            const uint32_t row = __umul24((uint32_t)k, (uint32_t)P.ny) + (uint32_t)j;
-            return (type)(__umul24(row, (uint32_t)P.nx) + (uint32_t)i);
+            const uint32_t row = mad_u24((uint32_t)k, (uint32_t)P.ny, (uint32_t)j);
+            return (type)mad_u24(row, (uint32_t)P.nx, (uint32_t)i);
         } else {
-            // f(i) = (i&3) + (i>>2)*64 = i + (i>>2)*60, and likewise for j (x4) and k (x16)
             if (BIG) {
                 const uint64_t brick = (uint64_t)((uint32_t)i >> 2) + (uint64_t)(uint32_t)P.bnx * ((uint64_t)((uint32_t)j >> 2) + (uint64_t)(uint32_t)P.bny * (uint64_t)((uint32_t)k >> 2));
                 return (type)(brick * 64u + (((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4)));
             }
-            const uint32_t fi = __umul24((uint32_t)i >> 2, 60u) + (uint32_t)i;
-            const uint32_t fj = __umul24((uint32_t)j >> 2, (uint32_t)P.bstride_y) + ((uint32_t)j << 2);
-            const uint32_t fk = __umul24((uint32_t)k >> 2, (uint32_t)P.bstride_z) + ((uint32_t)k << 4);
+            // (i&3) + (i>>2)*64 = i + (i>>2)*60, and likewise for j (x4) and k (x16)
+            const uint32_t fi = mad_u24((uint32_t)i >> 2, 60u, (uint32_t)i);
+            const uint32_t fj = mad_u24((uint32_t)j >> 2, P.bstride_y, (uint32_t)j << 2);
+            const uint32_t fk = mad_u24((uint32_t)k >> 2, P.bstride_z, (uint32_t)k << 4);
             return (type)(fi + fj + fk);
         }
     }
 };
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG>
-__global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
+// voxel fetch: buffer load with a 32-bit offset (hardware bounds check) when the volume
+// is below 4 GiB, plain global load otherwise
+template <typename VoxelT, bool BIG>
+struct VoxelFetch {
+    __device__ static __forceinline__ uint32_t load(const VoxelT *__restrict__ vol, __amdgpu_buffer_rsrc_t rs, typename std::conditional<BIG, uint64_t, uint32_t>::type off)
+    {
+        if (BIG) return (uint32_t)vol[off];
+        if (sizeof(VoxelT) == 1) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off, 0, 0);
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)(off << 1), 0, 0);
+    }
+};
+
+// Workgroup = 512 threads = 8 wavefronts = a 32x16-pixel tile (4x2 wave tiles of 8x8).
+// Blocks are handed to XCDs in chunks of FAST_CHUNK horizontally adjacent tiles; with an
+// odd number of chunks per tile row the owner (chunk index mod 8) rotates from row to row,
+// so every XCD gets an equal share of every image region (the hit pixels are a centred
+// blob) while x-neighbours, which share cache lines, stay on one XCD's L2.
+constexpr unsigned FAST_THREADS = 512, FAST_TILE_W = kFastTileW, FAST_TILE_H = kFastTileH, FAST_CHUNK = kFastChunk;
+
+struct FastGrid { unsigned tiles_x, tiles_y, chunks_per_row, blocks; };
+
+static inline FastGrid fast_grid(int img_w, int rows)
+{
+    FastGrid g;
+    g.tiles_x = (unsigned)((img_w + (int)FAST_TILE_W - 1) / (int)FAST_TILE_W);
+    g.tiles_y = (unsigned)((rows + (int)FAST_TILE_H - 1) / (int)FAST_TILE_H);
+    g.chunks_per_row = (g.tiles_x + FAST_CHUNK - 1) / FAST_CHUNK;
+    g.chunks_per_row |= 1u;                                   // odd: owners rotate per row
+    const unsigned chunks = g.chunks_per_row * g.tiles_y;
+    g.blocks = ((chunks + 7u) / 8u) * 8u * FAST_CHUNK;
+    return g;
+}
+
+__device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x, unsigned tiles_y,
+                                                   unsigned chunks_per_row, unsigned &tx, unsigned &ty)
+{
+    const unsigned xcd = b & 7u, slot = b >> 3;
+    const unsigned c = (slot / FAST_CHUNK) * 8u + xcd;       // chunk index, owner = c % 8
+    ty = c / chunks_per_row;
+    tx = (c % chunks_per_row) * FAST_CHUNK + (slot % FAST_CHUNK);
+    return ty < tiles_y && tx < tiles_x;
+}
+
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT>
+__global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
+                                                            const uint32_t vol_bytes,
                                                             float4 *__restrict__ fb,
                                                             uint32_t *__restrict__ spp,
-                                                            const unsigned tiles_x, const unsigned tiles_y)
+                                                            const unsigned tiles_x, const unsigned tiles_y,
+                                                            const unsigned chunks_per_row,
+                                                            const uint32_t *__restrict__ tile_table)
 {
+    __shared__ float2 lut[LUT ? FAST_LUT_MAX : 1];
+#ifdef VR_EXP_TRACE             // experiment only: per-wave start/end timestamps into spp
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     unsigned tx, ty;
-    tile_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty);
-    if (tx == 0xffffffffu) return;
+    if (tile_table) {                                       // host-built longest-first order
+        const uint32_t t = tile_table[blockIdx.x];
+        if (t == 0xffffffffu) return;                        // padding block
+        tx = t & 0xffffu; ty = t >> 16;
+    } else if (!fast_tile_of_block(blockIdx.x, tiles_x, tiles_y, chunks_per_row, tx, ty)) {
+        return;                                              // padding block
+    }
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const int lx = (int)(tx * 16u + (wave & 1u) * 8u + (lane & 7u));
-    const int ly = (int)(ty * 16u + (wave >> 1) * 8u + (lane >> 3));
+    const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + (lane & 7u));
+    const int ly = (int)(ty * FAST_TILE_H + (wave >> 2) * 8u + (lane >> 3));
     int px = lx, py;
     if (P.stripe_count > 1) {
         const int s = ly / P.stripe_rows, r = ly % P.stripe_rows;
@@ -336,13 +409,34 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
     } else {
         py = P.row_begin + ly;
     }
-    if (px >= P.col_lim || py >= P.row_lim || py >= P.row_end) return;
+    const bool in_image = !(px >= P.col_lim || py >= P.row_lim || py >= P.row_end);
 
-    const Ray ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+    Ray ray = {};
     float t_min = 0.0f, t_max = 0.0f;
+    bool hit = false;
+    if (in_image) {
+        ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+        hit = intersect_ray_aabb(P, ray, t_min, t_max);
+    }
+    if (LUT) {
+        // tabulate only if some ray of the workgroup enters the volume
+        if (__syncthreads_or(hit ? 1 : 0)) {
+            const int n = P.max_val - P.min_val + 1;
+            for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
+                const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
+                const float v = div_cert(s - P.fmin, P.fden, P.rden);
+                const float a = v * P.alpha_scale;
+                lut[e] = make_float2(v * a, a);
+            }
+            __syncthreads();
+        }
+    }
+    if (!in_image) return;
+
     float drgb = 0.0f, da = 0.0f;       // grey ramp: r == g == b bit for bit
     uint32_t fetches = 0;
-    if (intersect_ray_aabb(P, ray, t_min, t_max)) {
+    if (hit) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)vol_bytes, 0x00020000);
         const float EPSILON = 0.000001f;
         const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
         float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
@@ -374,7 +468,7 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
             if (k_safe > P.max_steps) k_safe = P.max_steps;
         }
 
-        // texcoord -> voxel index of the position (qx,qy,qz); valid (unclamped) inside the prefix
+        // texcoord -> voxel index of a position; valid (unclamped) inside the prefix
         auto voxel_of = [&](float ax, float ay, float az, int &vi, int &vj, int &vk) {
             const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
@@ -387,22 +481,22 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
             vj = (int)(tcy * P.fdim[1]);
             vk = (int)(tcz * P.fdim[2]);
         };
-        // window + grey-ramp classification + front-to-back compositing of one sample
-        auto composite = [&](float s) {
-            s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
-            s = div_cert(s - P.fmin, P.fden, P.rden);
-            const float a = s * P.alpha_scale;
-            const float c = s * a;
-            const float om = 1.0f - da;
-            drgb += c * om;
-            da += a * om;
+        // window + grey-ramp classification of one texel -> (c, a) of VolumeRenderer.cs:130-131
+        auto classify = [&](uint32_t texel, float &c, float &a) {
+            if (LUT) {
+                const int e = min(max((int)texel, P.min_val), P.max_val) - P.min_val;
+                const float2 ca = lut[e];
+                c = ca.x; a = ca.y;
+            } else {
+                float s = (float)texel;
+                s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
+                s = div_cert(s - P.fmin, P.fden, P.rden);
+                a = s * P.alpha_scale;
+                c = s * a;
+            }
         };
-
-        int i = 0;
-        bool done = false;
-        // ---- safe prefix, FAST_BATCH samples per trip
-        const int n_batched = k_safe - (k_safe % FAST_BATCH);
-        while (i < n_batched) {
+        // gathers of one batch: FAST_BATCH consecutive samples from the current position
+        auto issue = [&](uint32_t (&v)[FAST_BATCH]) {
             typename VoxelAddr<LAYOUT, BIG>::type off[FAST_BATCH];
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
@@ -411,23 +505,68 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
                 off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
                 qx += dsx; qy += dsy; qz += dsz;
             }
-            float v[FAST_BATCH];
-#pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) v[u] = (float)vol[off[u]];
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
-                if (!done) {
-                    if (da >= 0.95f) { done = true; }
-                    else {
-                        composite(v[u]);
-                        i++;
-                        if (da > 0.99f) done = true;
-                    }
-                }
+#if defined(VR_EXP_NOLOAD)      // experiment only: no memory access at all (VALU bound)
+                v[u] = (uint32_t)(off[u] & 4095u);
+#elif defined(VR_EXP_MASK)      // experiment only: fold all accesses into 1 MiB (cache-resident)
+                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u] & 0x7FFFFu);
+#else
+                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
+#endif
             }
-            if (done) break;
+        };
+        int i = 0;
+        // front-to-back compositing of one batch; returns true when the ray terminated.
+        // alpha_scale in [0,1] (fast-path precondition) makes dest.a non-decreasing and <= 1,
+        // so "dest.a < 0.95 before the LAST sample" proves the shader's per-sample test
+        // `dest.a >= 0.95 -> break` (VolumeRenderer.cs:118) passed for the whole batch; only
+        // the batch in which a ray terminates is replayed with the literal per-sample tests.
+        auto consume = [&](const uint32_t (&v)[FAST_BATCH]) -> bool {
+            float c[FAST_BATCH], a[FAST_BATCH];
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) classify(v[u], c[u], a[u]);
+            const float drgb0 = drgb, da0 = da;
+            float da_last = 0.0f;
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) {
+                if (u == FAST_BATCH - 1) da_last = da;
+                const float om = 1.0f - da;
+                drgb += c[u] * om;
+                da += a[u] * om;
+            }
+            if (da_last < 0.95f) { i += FAST_BATCH; return false; }
+            drgb = drgb0; da = da0;
+#pragma unroll
+            for (int u = 0; u < FAST_BATCH; u++) {
+                if (da >= 0.95f) return true;
+                const float om = 1.0f - da;
+                drgb += c[u] * om;
+                da += a[u] * om;
+                i++;
+            }
+            return da >= 0.95f;
+        };
+
+        bool done = false;
+        // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
+        //      while the current batch is composited
+        const int nb = k_safe / FAST_BATCH;
+        {
+            uint32_t va[FAST_BATCH], vb[FAST_BATCH];
+            int b = 0;
+            if (nb > 0) issue(va);
+            while (b < nb) {
+                if (b + 1 < nb) issue(vb);
+                if (consume(va)) { done = true; break; }
+                if (++b >= nb) break;
+                if (b + 1 < nb) issue(va);
+                if (consume(vb)) { done = true; break; }
+                ++b;
+            }
         }
-        // ---- checked tail: the shader's loop, literally
+        // ---- checked tail: the shader's loop, literally (dest.a > 0.99 of :134 is implied
+        //      by the dest.a >= 0.95 test of the next iteration and changes nothing)
         if (!done) {
             const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
             for (; i < P.max_steps; i++) {
@@ -443,8 +582,11 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
                 const int vi = min((int)(tcx * P.fdim[0]), nxm1);
                 const int vj = min((int)(tcy * P.fdim[1]), nym1);
                 const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-                composite((float)vol[VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)]);
-                if (da > 0.99f) { i++; break; }
+                float c, a;
+                classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, a);
+                const float om = 1.0f - da;
+                drgb += c * om;
+                da += a * om;
                 qx += dsx; qy += dsy; qz += dsz;
             }
         }
@@ -452,7 +594,17 @@ __global__ __launch_bounds__(256) void raymarch_fast_kernel(const FrameParams P,
     }
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
     fb[pix] = make_float4(drgb, drgb, drgb, da);
+#ifdef VR_EXP_TRACE
+    if (spp && (threadIdx.x & 63u) == 0) {
+        const unsigned w = blockIdx.x * 8u + (threadIdx.x >> 6);
+        const unsigned long long t1 = wall_clock64();
+        spp[w * 4u + 0] = (uint32_t)trace_t0; spp[w * 4u + 1] = (uint32_t)t1;
+        spp[w * 4u + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        spp[w * 4u + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#else
     if (spp) spp[pix] = fetches;
+#endif
 }
 
 // ------------------------------------------------------------------ helper kernels
@@ -585,29 +737,33 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG>
-static hipError_t launch_fast(const FrameParams &P, const void *vol, float4 *fb, uint32_t *spp, unsigned tiles_x,
-                              unsigned tiles_y, hipStream_t st)
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT>
+static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
+                              uint32_t *spp, int rows, hipStream_t st)
 {
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG>),
-                       dim3(padded_blocks(tiles_x, tiles_y)), dim3(256), 0, st, P, (const VoxelT *)vol, fb, spp,
-                       tiles_x, tiles_y);
+    const FastGrid g = fast_grid(P.img_w, rows);
+    const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT>), dim3(blocks),
+                       dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp,
+                       g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table);
     return hipGetLastError();
 }
 
 template <typename VoxelT, int LAYOUT>
 static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
-                                uint32_t *spp, unsigned tx, unsigned ty, hipStream_t st)
+                                uint32_t *spp, int rows, hipStream_t st)
 {
     const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
     const bool big = L.big_offsets != 0;
-#define VR_CASE(TC, VW, BG)                                                               \
-    if (L.divmode_tc == TC && view == VW && big == BG)                                    \
-        return launch_fast<VoxelT, LAYOUT, TC, VW, BG>(P, vol, fb, spp, tx, ty, st);
-    VR_CASE(DIV_UNIT, 0, false) VR_CASE(DIV_UNIT, 1, false) VR_CASE(DIV_UNIT, 2, false)
-    VR_CASE(DIV_CERT, 0, false) VR_CASE(DIV_CERT, 1, false) VR_CASE(DIV_CERT, 2, false)
-    VR_CASE(DIV_UNIT, 0, true) VR_CASE(DIV_UNIT, 1, true) VR_CASE(DIV_UNIT, 2, true)
-    VR_CASE(DIV_CERT, 0, true) VR_CASE(DIV_CERT, 1, true) VR_CASE(DIV_CERT, 2, true)
+    const bool lut = L.use_lut != 0;
+#define VR_CASE(TC, VW, BG, LT)                                                           \
+    if (L.divmode_tc == TC && view == VW && big == BG && lut == LT)                       \
+        return launch_fast<VoxelT, LAYOUT, TC, VW, BG, LT>(P, L, vol, fb, spp, rows, st);
+#define VR_CASES(BG, LT)                                                                  \
+    VR_CASE(DIV_UNIT, 0, BG, LT) VR_CASE(DIV_UNIT, 1, BG, LT) VR_CASE(DIV_UNIT, 2, BG, LT) \
+    VR_CASE(DIV_CERT, 0, BG, LT) VR_CASE(DIV_CERT, 1, BG, LT) VR_CASE(DIV_CERT, 2, BG, LT)
+    VR_CASES(false, true) VR_CASES(false, false) VR_CASES(true, true) VR_CASES(true, false)
+#undef VR_CASES
 #undef VR_CASE
     return hipErrorInvalidValue;
 }
@@ -617,13 +773,12 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
 {
     return !L.generic && L.filter == 0 && L.mip == 0 && P.accum == 0 && P.tf_len <= 1 && P.fden > 0.0f &&
-           P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT;
+           P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT &&
+           P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f;
 }
 
-hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
-                           float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name)
+int launch_local_rows(const FrameParams &P)
 {
-    // local image rows covered by this launch
     int rows;
     if (P.stripe_count > 1) {
         const int nstripes_total = (P.img_h + P.stripe_rows - 1) / P.stripe_rows;
@@ -632,6 +787,13 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     } else {
         rows = P.row_end - P.row_begin;
     }
+    return rows;
+}
+
+hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                           float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name)
+{
+    const int rows = launch_local_rows(P);   // local image rows covered by this launch
     if (rows <= 0 || P.img_w <= 0) return hipSuccess;
     const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
     const bool count = spp != nullptr;
@@ -639,7 +801,7 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     if (kernel_name) *kernel_name = fast ? "raymarch_fast_kernel" : "raymarch_generic_kernel";
 #define VR_GO(T, LAY)                                                                                        \
     do {                                                                                                      \
-        if (fast) return dispatch_fast<T, LAY>(P, L, vol, fb, spp, tiles_x, tiles_y, st);                     \
+        if (fast) return dispatch_fast<T, LAY>(P, L, vol, fb, spp, rows, st);                                 \
         return count ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)             \
                      : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);           \
     } while (0)

@@ -18,7 +18,8 @@ import numpy as np
 
 _PKG_DIR = Path(__file__).resolve().parent
 _REPO_ROOT = _PKG_DIR.parent
-LIB_PATH = _PKG_DIR / "lib" / "libvr_core.so"
+# VR_CORE_LIB: experiment hook -- load an alternative build of the same C ABI
+LIB_PATH = Path(os.environ["VR_CORE_LIB"]).resolve() if os.environ.get("VR_CORE_LIB") else _PKG_DIR / "lib" / "libvr_core.so"
 HEADER_PATH = _REPO_ROOT / "include" / "vr_core.h"
 
 VR_OK, VR_E_INVALID, VR_E_NO_DEVICE, VR_E_HIP, VR_E_IO, VR_E_NOMEM = range(6)
