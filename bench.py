@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--alpha", type=float, default=0.004)
     ap.add_argument("--filter", choices=("nearest", "trilinear"), default="nearest")
-    ap.add_argument("--layout", choices=("linear", "bricked"), default=os.environ.get("VR_BENCH_LAYOUT", "linear"))
+    ap.add_argument("--layout", choices=("linear", "bricked"), default=os.environ.get("VR_BENCH_LAYOUT", "bricked"))
     ap.add_argument("--partition", choices=("stripes", "contiguous"), default="stripes")
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")

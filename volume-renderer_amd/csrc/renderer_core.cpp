@@ -33,7 +33,7 @@ RendererCore::RendererCore(int device) : main_cam(30), histogram(256, 0.0f), dev
         check(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking), "hipStreamCreate");
         check(hipEventCreate(&ev0_), "hipEventCreate");
         check(hipEventCreate(&ev1_), "hipEventCreate");
-        check(hipMalloc(&d_scratch_, sizeof(unsigned) * 260), "hipMalloc(scratch)");
+        check(hipMalloc(&d_scratch_, sizeof(unsigned) * 264), "hipMalloc(scratch)");
     }
 }
 
@@ -278,16 +278,19 @@ void RendererCore::setLayout(int lay)
 // min/max scan of src/RendererCore.cpp:360-384 as a device reduction
 void RendererCore::scanDatasetRange()
 {
+    // scratch: [0..1] reference-style min/max (index 8390640 skipped), [2..3] exact min/max
+    const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
+    check(hipMemcpyAsync(d_scratch_, init, sizeof(init), hipMemcpyHostToDevice, stream()), "hipMemcpy(scratch)");
+    check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
+                       vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 0, 1.0f,
+                       d_scratch_, d_scratch_ + 4, stream()),
+          "stats_kernel");
+    unsigned mm[4];
+    check(hipMemcpyAsync(mm, d_scratch_, sizeof(mm), hipMemcpyDeviceToHost, stream()), "hipMemcpy(scratch)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    exact_min_ = (int)mm[2];
+    exact_max_ = (int)mm[3];
     if (datasize_bytes == 2) {
-        const unsigned init[2] = {0xffffffffu, 0u};
-        check(hipMemcpyAsync(d_scratch_, init, sizeof(init), hipMemcpyHostToDevice, stream()), "hipMemcpy(scratch)");
-        check(launch_stats(d_vol_, 2, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
-                           vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 0,
-                           1.0f, d_scratch_, d_scratch_ + 2, stream()),
-              "stats_kernel");
-        unsigned mm[2];
-        check(hipMemcpyAsync(mm, d_scratch_, sizeof(mm), hipMemcpyDeviceToHost, stream()), "hipMemcpy(scratch)");
-        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
         // reference initial values: max_value = -1, min_value = 9000000
         const int mx = mm[1] == 0u && mm[0] == 0xffffffffu ? -1 : (int)mm[1];
         const int mn = mm[0] == 0xffffffffu ? 9000000 : (int)mm[0];
@@ -303,13 +306,13 @@ void RendererCore::computeHistogram(float out[256])
 {
     requireDevice("histogram");
     if (!d_vol_) throw std::runtime_error("histogram: no dataset loaded");
-    check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned) * 260, stream()), "hipMemset(scratch)");
+    check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned) * 264, stream()), "hipMemset(scratch)");
     check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
                        vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 1,
-                       (float)max_dataset_val, d_scratch_, d_scratch_ + 2, stream()),
+                       (float)max_dataset_val, d_scratch_, d_scratch_ + 4, stream()),
           "stats_kernel");
     unsigned counts[256];
-    check(hipMemcpyAsync(counts, d_scratch_ + 2, sizeof(counts), hipMemcpyDeviceToHost, stream()), "hipMemcpy(hist)");
+    check(hipMemcpyAsync(counts, d_scratch_ + 4, sizeof(counts), hipMemcpyDeviceToHost, stream()), "hipMemcpy(hist)");
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
     // src/RendererCore.cpp:361,400-405: the normaliser starts from the dataset max
     // (16-bit) or -1 (8-bit) and is raised to the largest bin count
@@ -546,6 +549,9 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         L.vol_bytes32 = small ? (uint32_t)bytes : 0u;
         const int64_t width = (int64_t)u_.max_val - (int64_t)u_.min_val + 1;
         L.use_lut = (width >= 2 && width <= 4096) ? 1 : 0;
+        L.lut_noclamp = (exact_min_ >= u_.min_val && exact_max_ <= u_.max_val) ? 1 : 0;
+        auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+        L.pow2_dims = (is_pow2(nx) && is_pow2(ny) && is_pow2(nz)) ? 1 : 0;
     }
     // division strategy: unit extents need no division at all; other divisors use the
     // 3-op Markstein quotient only after an exhaustive on-device certification

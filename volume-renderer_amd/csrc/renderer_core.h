@@ -113,8 +113,9 @@ private:
     float4 *d_tf_ = nullptr;
     uint32_t *d_spp_ = nullptr;
     size_t spp_capacity_ = 0;
-    unsigned *d_scratch_ = nullptr;          // 2 + 256 words
+    unsigned *d_scratch_ = nullptr;          // 4 + 256 words (+ slack)
     std::vector<float> tf_lut_;              // 256 x RGBA, empty = grey ramp
+    int exact_min_ = 0, exact_max_ = 65535;   // exact voxel range of the resident volume
     int row_begin_ = 0, row_end_ = -1;
     int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;
     bool fb_compact_ = false;

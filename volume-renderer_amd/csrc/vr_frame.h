@@ -47,6 +47,8 @@ struct LaunchConfig {
     int generic;                   // force the generic (always-checked) kernel
     int big_offsets;               // voxel offsets need 64-bit arithmetic
     int use_lut;                   // LDS classification table (window width <= 4096 entries)
+    int lut_noclamp;               // exact dataset range lies inside the window
+    int pow2_dims;                 // nx, ny, nz are powers of two
     uint32_t vol_bytes32;          // volume allocation size for the buffer descriptor (!big)
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;

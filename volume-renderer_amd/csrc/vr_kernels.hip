@@ -301,10 +301,17 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 constexpr int FAST_BATCH = VR_FAST_BATCH;
 constexpr int FAST_LUT_MAX = 4096;      // entries (x 8 B = 32 KiB of the CU's 160 KiB LDS)
 
+__device__ __forceinline__ int med3_i32(int a, int b, int c)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
 
@@ -325,11 +332,14 @@ struct VoxelAddr {
                 const uint64_t brick = (uint64_t)((uint32_t)i >> 2) + (uint64_t)(uint32_t)P.bnx * ((uint64_t)((uint32_t)j >> 2) + (uint64_t)(uint32_t)P.bny * (uint64_t)((uint32_t)k >> 2));
                 return (type)(brick * 64u + (((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4)));
             }
-            // (i&3) + (i>>2)*64 = i + (i>>2)*60, and likewise for j (x4) and k (x16)
-            const uint32_t fi = mad_u24((uint32_t)i >> 2, 60u, (uint32_t)i);
-            const uint32_t fj = mad_u24((uint32_t)j >> 2, P.bstride_y, (uint32_t)j << 2);
-            const uint32_t fk = mad_u24((uint32_t)k >> 2, P.bstride_z, (uint32_t)k << 4);
-            return (type)(fi + fj + fk);
+            // (i&3) + (i>>2)*64 = i + (i>>2)*60, likewise j (x4) and k (x16):
+            //   offset = [i + 4j + 16k] + 60*(i>>2) + bstride_y*(j>>2) + bstride_z*(k>>2)
+            // = 2 shift-adds + 3 shifts + 3 chained 24-bit mads
+            uint32_t t = ((uint32_t)j << 2) + (uint32_t)i;
+            t = ((uint32_t)k << 4) + t;
+            t = mad_u24((uint32_t)i >> 2, 60u, t);
+            t = mad_u24((uint32_t)j >> 2, P.bstride_y, t);
+            return (type)mad_u24((uint32_t)k >> 2, P.bstride_z, t);
         }
     }
 };
@@ -377,7 +387,12 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
     return ty < tiles_y && tx < tiles_x;
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT>
+// POW2: every volume dimension is a power of two and the box extents are 1 (DIV_UNIT), so
+// texcoord*N is an exact scaling and the prefix can be marched in voxel units:
+// fl(q*S + ds*S) == S*fl(q + ds) for a power-of-two S, bit for bit (also in the subnormal
+// range, where fp32 addition is exact), which drops the three per-sample multiplies.
+// NOCLAMP: the dataset's exact min/max lie inside the window, so clamp() is the identity.
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP>
 __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const uint32_t vol_bytes,
@@ -431,11 +446,10 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
             __syncthreads();
         }
     }
-    if (!in_image) return;
 
     float drgb = 0.0f, da = 0.0f;       // grey ramp: r == g == b bit for bit
     uint32_t fetches = 0;
-    if (hit) {
+    {                                   // every thread runs the (barrier-carrying) batch loop
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)vol_bytes, 0x00020000);
         const float EPSILON = 0.000001f;
         const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
@@ -466,6 +480,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
             if (ok && kmax > 4.0f) k_safe = (int)(kmax * 0.999f) - 2;
             if (!(k_safe > 0)) k_safe = 0;
             if (k_safe > P.max_steps) k_safe = P.max_steps;
+            if (!hit) k_safe = 0;
         }
 
         // texcoord -> voxel index of a position; valid (unclamped) inside the prefix
@@ -481,11 +496,13 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
             vj = (int)(tcy * P.fdim[1]);
             vk = (int)(tcz * P.fdim[2]);
         };
+        const int lut_bias = -8 * P.min_val;             // byte offset of entry 0 relative to texel*8
         // window + grey-ramp classification of one texel -> (c, a) of VolumeRenderer.cs:130-131
         auto classify = [&](uint32_t texel, float &c, float &a) {
             if (LUT) {
-                const int e = min(max((int)texel, P.min_val), P.max_val) - P.min_val;
-                const float2 ca = lut[e];
+                int t = (int)texel;
+                if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);   // clamp(texel, min_val, max_val), min <= max
+                const float2 ca = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lut) + (uint32_t)((t << 3) + lut_bias));
                 c = ca.x; a = ca.y;
             } else {
                 float s = (float)texel;
@@ -495,15 +512,30 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 c = s * a;
             }
         };
+        // POW2: per box axis the scale is the dimension of the voxel axis it maps to
+        const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
+        float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
+        const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
+        const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
         // gathers of one batch: FAST_BATCH consecutive samples from the current position
         auto issue = [&](uint32_t (&v)[FAST_BATCH]) {
             typename VoxelAddr<LAYOUT, BIG>::type off[FAST_BATCH];
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
                 int vi, vj, vk;
-                voxel_of(qx, qy, qz, vi, vj, vk);
+                if (POW2) {
+                    // voxel units: Q = q*S, U = Q + half*S = texcoord*S before the flips
+                    const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+                    float fx = ux, fy = uy, fz = uz;
+                    if (VIEW == 1) { fy = Sz - uz; fz = uy; }
+                    else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                    vi = (int)fx; vj = (int)fy; vk = (int)fz;
+                    Qx += dSx; Qy += dSy; Qz += dSz;
+                } else {
+                    voxel_of(qx, qy, qz, vi, vj, vk);
+                    qx += dsx; qy += dsy; qz += dsz;
+                }
                 off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
-                qx += dsx; qy += dsy; qz += dsz;
             }
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
@@ -552,22 +584,32 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
         //      while the current batch is composited
         const int nb = k_safe / FAST_BATCH;
+        // The 8 wavefronts of a workgroup advance in lockstep (one barrier per two batches):
+        // their rays cross the same voxel rows / bricks at the same time, so a cache line
+        // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
             uint32_t va[FAST_BATCH], vb[FAST_BATCH];
             int b = 0;
-            if (nb > 0) issue(va);
-            while (b < nb) {
-                if (b + 1 < nb) issue(vb);
-                if (consume(va)) { done = true; break; }
-                if (++b >= nb) break;
-                if (b + 1 < nb) issue(va);
-                if (consume(vb)) { done = true; break; }
-                ++b;
+            bool fin = nb == 0;
+            if (!fin) issue(va);
+            for (;;) {
+                if (__syncthreads_and(fin ? 1 : 0)) break;
+                if (!fin) {
+                    if (b + 1 < nb) issue(vb);
+                    if (consume(va)) { done = true; fin = true; }
+                    else if (++b >= nb) fin = true;
+                }
+                if (!fin) {
+                    if (b + 1 < nb) issue(va);
+                    if (consume(vb)) { done = true; fin = true; }
+                    else if (++b >= nb) fin = true;
+                }
             }
         }
+        if (POW2) { qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz; }   // exact: S is a power of two
         // ---- checked tail: the shader's loop, literally (dest.a > 0.99 of :134 is implied
         //      by the dest.a >= 0.95 test of the next iteration and changes nothing)
-        if (!done) {
+        if (hit && !done) {
             const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
             for (; i < P.max_steps; i++) {
                 const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
@@ -592,6 +634,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         }
         fetches = (uint32_t)i;
     }
+    if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
     fb[pix] = make_float4(drgb, drgb, drgb, da);
 #ifdef VR_EXP_TRACE
@@ -685,18 +728,17 @@ __global__ __launch_bounds__(256) void stats_kernel(const VoxelT *__restrict__ v
                                                     int pass, float scale255, unsigned *minmax, unsigned *hist)
 {
     __shared__ unsigned lh[256];
-    __shared__ unsigned lmin, lmax;
     if (threadIdx.x < 256) lh[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { lmin = 0xffffffffu; lmax = 0; }
     __syncthreads();
     const uint64_t total = (uint64_t)nx * ny * nz;
-    unsigned mn = 0xffffffffu, mx = 0;
+    unsigned mn = 0xffffffffu, mx = 0, xmn = 0xffffffffu, xmx = 0;
     for (uint64_t lin = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total;
          lin += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t i = (uint32_t)(lin % nx), j = (uint32_t)((lin / nx) % ny), k = (uint32_t)(lin / ((uint64_t)nx * ny));
         const unsigned v = vol[storage_index(layout, i, j, k, nx, ny, bnx, bny)];
         if (pass == 0) {
-            if (lin == 8390640ull) continue;
+            xmn = v < xmn ? v : xmn; xmx = v > xmx ? v : xmx;        // exact range (kernel selection)
+            if (lin == 8390640ull) continue;                          // reference scan skips this index
             mn = v < mn ? v : mn; mx = v > mx ? v : mx;
         } else {
             unsigned bin = v;
@@ -709,9 +751,15 @@ __global__ __launch_bounds__(256) void stats_kernel(const VoxelT *__restrict__ v
         }
     }
     if (pass == 0) {
-        atomicMin(&lmin, mn); atomicMax(&lmax, mx);
-        __syncthreads();
-        if (threadIdx.x == 0) { atomicMin(&minmax[0], lmin); atomicMax(&minmax[1], lmax); }
+        // wave-level then one atomic per wave
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (unsigned)__shfl_xor((int)mn, o)); mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+            xmn = min(xmn, (unsigned)__shfl_xor((int)xmn, o)); xmx = max(xmx, (unsigned)__shfl_xor((int)xmx, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&minmax[0], mn); atomicMax(&minmax[1], mx);
+            atomicMin(&minmax[2], xmn); atomicMax(&minmax[3], xmx);
+        }
     } else {
         __syncthreads();
         if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
@@ -737,16 +785,37 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP>
 static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
                               uint32_t *spp, int rows, hipStream_t st)
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT>), dim3(blocks),
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp,
                        g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table);
     return hipGetLastError();
+}
+
+template <typename VoxelT, int LAYOUT, int VIEW, bool BIG>
+static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
+                                 uint32_t *spp, int rows, hipStream_t st)
+{
+    const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
+    const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+    if (L.divmode_tc == DIV_CERT) {
+        if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, true, false, true>(P, L, vol, fb, spp, rows, st)
+                                : launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, true, false, false>(P, L, vol, fb, spp, rows, st);
+        return launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, false, false, false>(P, L, vol, fb, spp, rows, st);
+    }
+    if (pow2) {
+        if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, true, true>(P, L, vol, fb, spp, rows, st)
+                                : launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, true, false>(P, L, vol, fb, spp, rows, st);
+        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, false, true, false>(P, L, vol, fb, spp, rows, st);
+    }
+    if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, false, true>(P, L, vol, fb, spp, rows, st)
+                            : launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, false, false>(P, L, vol, fb, spp, rows, st);
+    return launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, false, false, false>(P, L, vol, fb, spp, rows, st);
 }
 
 template <typename VoxelT, int LAYOUT>
@@ -754,18 +823,14 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
                                 uint32_t *spp, int rows, hipStream_t st)
 {
     const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
-    const bool big = L.big_offsets != 0;
-    const bool lut = L.use_lut != 0;
-#define VR_CASE(TC, VW, BG, LT)                                                           \
-    if (L.divmode_tc == TC && view == VW && big == BG && lut == LT)                       \
-        return launch_fast<VoxelT, LAYOUT, TC, VW, BG, LT>(P, L, vol, fb, spp, rows, st);
-#define VR_CASES(BG, LT)                                                                  \
-    VR_CASE(DIV_UNIT, 0, BG, LT) VR_CASE(DIV_UNIT, 1, BG, LT) VR_CASE(DIV_UNIT, 2, BG, LT) \
-    VR_CASE(DIV_CERT, 0, BG, LT) VR_CASE(DIV_CERT, 1, BG, LT) VR_CASE(DIV_CERT, 2, BG, LT)
-    VR_CASES(false, true) VR_CASES(false, false) VR_CASES(true, true) VR_CASES(true, false)
-#undef VR_CASES
-#undef VR_CASE
-    return hipErrorInvalidValue;
+    if (L.big_offsets) {
+        if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, true>(P, L, vol, fb, spp, rows, st);
+        if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, true>(P, L, vol, fb, spp, rows, st);
+        return dispatch_fast2<VoxelT, LAYOUT, 2, true>(P, L, vol, fb, spp, rows, st);
+    }
+    if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, false>(P, L, vol, fb, spp, rows, st);
+    if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, false>(P, L, vol, fb, spp, rows, st);
+    return dispatch_fast2<VoxelT, LAYOUT, 2, false>(P, L, vol, fb, spp, rows, st);
 }
 
 // The specialised kernel covers NEAREST / composite / iterative / grey ramp with a
