@@ -105,6 +105,17 @@ int vr_get_dataset_range(vr_handle h, int *min_val, int *max_val);
 /* 256-bin display histogram (src/RendererCore.cpp:386-405) */
 int vr_histogram(vr_handle h, float hist256[256]);
 
+/* ---- PVM / DDS codec (host only, no handle): readPVMvolume of the reference's
+        include/ddsbase.h:29-35 (src/ddsbase.cpp:768-858).  Returns a malloc'ed payload of
+        width*height*depth*components bytes (free with vr_free) or NULL; 16-bit payloads
+        are big-endian as stored (V^3 convention). ---------------------- */
+unsigned char *vr_read_pvm_volume(const char *filename, unsigned int *width, unsigned int *height,
+                                  unsigned int *depth, unsigned int *components, float *scalex,
+                                  float *scaley, float *scalez);
+/* the reference's checksum() (src/ddsbase.cpp:869-893) */
+unsigned int vr_checksum(const unsigned char *data, unsigned int bytes);
+void vr_free(void *p);
+
 /* ---- uniforms: setAlpha / setMIP / setInitialCameraRotation / setMinVal /
         setMaxVal (src/RendererCore.cpp:56-98; RendererGUI.cpp:336-358,382-385) -- */
 int vr_set_alpha(vr_handle h, float alpha_scale);

@@ -1,0 +1,161 @@
+"""CPU-side tests of the drop-in boundary: libvr_core.so loads, exports every symbol the
+header declares, and the host logic (camera, .raw.inf grammar, transfer function, error
+paths) behaves like the reference's RendererCore.  No compute call needs a GPU; GPU
+operations must FAIL LOUDLY here (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(vra):
+    lib = vra.load_library()
+    names = vra.symbols_declared_in_header()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert {"vr_create", "vr_setup", "vr_render", "vr_read_volume_file", "vr_set_volume", "vr_camera_orient",
+            "vr_set_alpha", "vr_set_mip", "vr_set_view", "vr_set_window", "vr_kernel_ms_take", "vr_read_pixels",
+            "vr_take_message", "vr_load_shader", "vr_save_image", "vr_read_pvm_volume"} <= set(names)
+
+
+def test_no_cpu_fallback_gpu_operations_fail_loudly(vra):
+    r = vra.RendererCore(-1)          # host-only handle
+    r.setup((64, 64))
+    assert r.loadShader("VolumeRenderer.cs")
+    for call in (lambda: r.render(), lambda: r.renderAsync(), lambda: r.readPixels(),
+                 lambda: r.setVolume(np.zeros((4, 4, 4), dtype=np.uint8)),
+                 lambda: r.generateSynthetic(0, (8, 8, 8), 1, 3), lambda: r.countSamples(), lambda: r.histogram()):
+        with pytest.raises(vra.VRError) as e:
+            call()
+        assert e.value.code == vra.renderer.VR_E_NO_DEVICE
+    r.close()
+
+
+def test_create_on_missing_device_reports_no_device(vra):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(vra.VRError) as e:
+        vra.RendererCore(0)
+    assert e.value.code == vra.renderer.VR_E_NO_DEVICE
+
+
+def test_camera_through_capi_matches_oracle_camera(vra, oracle):
+    r = vra.RendererCore(-1)
+    c = oracle.Camera()
+    assert np.array_equal(r.getCameraBlock().view(np.uint32), c.block().view(np.uint32))
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            args = (float(rng.choice([-1.0, 1.0])), 0.0, 0.0)              # scroll zoom (GlfwManager.cpp:213)
+        else:
+            args = (0.0, float(rng.choice([-0.06, 0.0, 0.06])), float(rng.choice([-0.06, 0.06])))   # drag (:179)
+        r.cameraOrient(*args)
+        c.orient(*args)
+        assert np.array_equal(r.getCameraBlock().view(np.uint32), c.block().view(np.uint32)), args
+    r.resetCamera(); c.reset()
+    assert np.array_equal(r.getCameraBlock().view(np.uint32), c.block().view(np.uint32))
+    blk = np.arange(21, dtype=np.float32)
+    r.setCameraBlock(blk)
+    got = r.getCameraBlock()
+    assert np.array_equal(got[:19], blk[:19]) and got[19] == 1.0 and got[20] == 20.0
+    r.close()
+
+
+def test_shader_and_workgroup_bookkeeping(vra):
+    r = vra.RendererCore(-1)
+    r.setup((1920, 1080))
+    assert r.loaded_shader == ""
+    assert r.loadShader("shaders/VolumeRenderer.cs")
+    assert r.loaded_shader == "VolumeRenderer.cs"                     # basename, RendererCore.cpp:499-500
+    assert r.takeMessage() == ("Shader Loaded!", "Shader Loaded Successfully!")
+    assert r.takeMessage() is None
+    assert r.workgroups == (120, 68)                                  # Q1 fixed: ceil-div
+    r.setQuirks(vra.renderer.QUIRK_TRUNC_GRID)
+    assert r.workgroups == (120, 67)                                  # reference: 1080/16 = 67 (RendererCore.cpp:121-122)
+    assert not r.loadShader("")
+    r.close()
+
+
+def test_raw_inf_grammar_and_sidecar_writing(vra, tmp_path):
+    r = vra.RendererCore(-1)
+    r.setup((32, 32))
+    raw = tmp_path / "vol.raw"
+    raw.write_bytes(bytes(range(24)))
+    assert not r.checkRawInfFile(raw)
+    # no sidecar: dims/spacing typed into the GUI are used and the sidecar is written
+    r.setDims(4, 3, 2); r.setSpacing(1.0, 0.5, 2.0)
+    with pytest.raises(vra.VRError) as e:
+        r.readVolumeData(raw, 1)
+    assert e.value.code == vra.renderer.VR_E_NO_DEVICE                # parsed fine, upload needs a GPU
+    assert r.checkRawInfFile(raw)
+    text = (tmp_path / "vol.raw.inf").read_text()
+    assert text == "#dimensions\n4 3 2\n\n#voxel-spacing\n1 0.5 2\n"
+    # malformed sidecars produce the reference's GUI messages
+    cases = {
+        "#dimensions\n\n#voxel-spacing\n1 1 1\n": "Dimensions for Volume Data not provided",
+        "#voxel-spacing\n1 1 1\n": "Make sure the header is \"#dimesnsions\"",
+        "#dimensions\n4 3 2\n": "Make sure the header is \"#voxel-spacing\"",
+        "#dimensions\n4 3 2\n#voxel-spacing\n\n": "Aspect Ratio for Volume Data not provided",
+        "#dimensions\n0 3 2\n#voxel-spacing\n1 1 1\n": "shouldn't contain any zeroes",
+    }
+    for body, expect in cases.items():
+        (tmp_path / "vol.raw.inf").write_text(body)
+        with pytest.raises(vra.VRError) as e:
+            r.readVolumeData(raw, 1)
+        assert e.value.code == vra.renderer.VR_E_IO, body
+        title, msg = r.takeMessage()
+        assert expect in msg, (body, msg)
+    # blank lines and unknown headers are tolerated
+    (tmp_path / "vol.raw.inf").write_text("\n#comment\n#dimensions\n4 3 2\n\n\n#voxel-spacing\n1 1 1\n\n")
+    with pytest.raises(vra.VRError) as e:
+        r.readVolumeData(raw, 1)
+    assert e.value.code == vra.renderer.VR_E_NO_DEVICE
+    with pytest.raises(vra.VRError) as e:
+        r.readVolumeData(tmp_path / "missing.raw", 1)
+    with pytest.raises(vra.VRError):
+        r.readVolumeData(raw, 3)                                       # datasize_bytes must be 1|2
+    r.close()
+
+
+def test_transfer_function_lut_matches_oracle_spline(vra, oracle):
+    r = vra.RendererCore(-1)
+    grey = r.getTransferLut()
+    assert np.allclose(grey[:, 0], np.arange(256) / 255.0)
+    iso = [0, 141, 149, 255]        # AlphaControlSplineWidget.cpp:56-59 default alpha knots
+    rgba = [[0, 0, 0, 0], [0, 0, 0, 0.759], [0, 0, 0, 0.45], [0, 0, 0, 1]]
+    r.setTransferFunction(iso, rgba)
+    assert np.array_equal(r.getTransferLut().view(np.uint32), oracle.spline_tf(iso, rgba).view(np.uint32))
+    rng = np.random.default_rng(5)
+    for n in (2, 3, 7):
+        iso = np.sort(rng.choice(256, size=n, replace=False))
+        rgba = rng.random((n, 4)).astype(np.float32)
+        r.setTransferFunction(iso, rgba)
+        assert np.array_equal(r.getTransferLut().view(np.uint32), oracle.spline_tf(iso, rgba).view(np.uint32))
+    with pytest.raises(vra.VRError):
+        r.setTransferFunction([5, 5], [[0, 0, 0, 0], [1, 1, 1, 1]])    # iso values must ascend
+    with pytest.raises(vra.VRError):
+        r.setTransferFunction([5], [[0, 0, 0, 0]])
+    r.setTransferFunction()                                            # back to the grey ramp
+    assert np.array_equal(r.getTransferLut(), grey)
+    r.close()
+
+
+def test_argument_validation(vra):
+    r = vra.RendererCore(-1)
+    with pytest.raises(vra.VRError):
+        r.setup((0, 10))
+    for bad in (lambda: r.setFilter(7), lambda: r.setAccum(-1), lambda: r.setLayout(5), lambda: r.setRowRange(5, 2),
+                lambda: r.setRowStripes(0, 0, 2), lambda: r.setRowStripes(8, 3, 2), lambda: r.setKernelVariant(9)):
+        with pytest.raises(vra.VRError) as e:
+            bad()
+        assert e.value.code == vra.renderer.VR_E_INVALID
+    r.close()
+    lib = vra.load_library()
+    assert lib.vr_render(None) == vra.renderer.VR_E_INVALID            # null handle
+    assert lib.vr_create(None, -1) == vra.renderer.VR_E_INVALID

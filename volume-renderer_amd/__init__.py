@@ -13,7 +13,9 @@ from .renderer import (  # noqa: F401
     RendererCore,
     VRError,
     build_library,
+    checksum,
     load_library,
+    read_pvm_volume,
     symbols_declared_in_header,
 )
 
@@ -22,6 +24,8 @@ __all__ = [
     "RendererCore",
     "VRError",
     "build_library",
+    "checksum",
     "load_library",
+    "read_pvm_volume",
     "symbols_declared_in_header",
 ]

@@ -2,12 +2,14 @@
 // vr::RendererCore.  Plays the role of the reference's `friend class RendererGUI`
 // (include/RendererCore.h:18): it writes the public fields and calls the set*()
 // methods exactly where the GUI does (file:line per function in vr_core.h).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "../../include/vr_core.h"
 #include "renderer_core.h"
+#include "volume_io.h"
 
 struct vr_renderer {
     vr::RendererCore core;
@@ -394,6 +396,47 @@ int vr_save_image(vr_handle h, const char *path, const char *ext)
     });
     return g != VR_OK ? g : rc;
 }
+
+unsigned char *vr_read_pvm_volume(const char *filename, unsigned int *width, unsigned int *height,
+                                  unsigned int *depth, unsigned int *components, float *scalex, float *scaley,
+                                  float *scalez)
+{
+    if (!filename) return nullptr;
+    vr::PvmVolume v;
+    std::string err;
+    try {
+        if (!vr::readPVMvolume(filename, v, err)) { g_create_error = err; return nullptr; }
+    } catch (const std::exception &e) {
+        g_create_error = e.what();
+        return nullptr;
+    }
+    if (!components && v.components != 1) { g_create_error = "multi-component PVM needs a components pointer"; return nullptr; }
+    unsigned char *out = static_cast<unsigned char *>(std::malloc(v.data.size() ? v.data.size() : 1));
+    if (!out) return nullptr;
+    std::memcpy(out, v.data.data(), v.data.size());
+    if (width) *width = v.width;
+    if (height) *height = v.height;
+    if (depth) *depth = v.depth;
+    if (components) *components = v.components;
+    if (scalex) *scalex = v.scalex;
+    if (scaley) *scaley = v.scaley;
+    if (scalez) *scalez = v.scalez;
+    return out;
+}
+
+unsigned int vr_checksum(const unsigned char *data, unsigned int bytes)
+{
+    // sum of cipher*value with cipher = 271*cipher + value (mod 2^32), cipher0 = 1
+    unsigned int sum = 0, cipher = 1;
+    for (unsigned int i = 0; i < bytes; i++) {
+        const unsigned int v = data[i];
+        cipher = 271u * cipher + v;
+        sum += cipher * v;
+    }
+    return sum;
+}
+
+void vr_free(void *p) { std::free(p); }
 
 const char *vr_last_kernel_name(vr_handle h) { return h ? h->core.lastKernelName() : ""; }
 

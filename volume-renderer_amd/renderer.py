@@ -122,6 +122,9 @@ def load_library() -> C.CDLL:
         "vr_read_pixels": (i32, [h, C.POINTER(f32), C.c_size_t]),
         "vr_save_image": (i32, [h, C.c_char_p, C.c_char_p]),
         "vr_last_kernel_name": (C.c_char_p, [h]),
+        "vr_read_pvm_volume": (C.c_void_p, [C.c_char_p] + [C.POINTER(C.c_uint)] * 4 + [C.POINTER(f32)] * 3),
+        "vr_checksum": (C.c_uint, [C.c_void_p, C.c_uint]),
+        "vr_free": (None, [C.c_void_p]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)   # AttributeError = header/library drift: fail loudly
@@ -129,6 +132,25 @@ def load_library() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def read_pvm_volume(path):
+    """readPVMvolume through the C ABI -> (payload uint8 array, (w, h, d, components), (sx, sy, sz)) or None"""
+    lib = load_library()
+    w, h, d, c = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint()
+    sx, sy, sz = C.c_float(), C.c_float(), C.c_float()
+    p = lib.vr_read_pvm_volume(str(path).encode(), w, h, d, c, sx, sy, sz)
+    if not p:
+        return None
+    n = w.value * h.value * d.value * c.value
+    data = np.frombuffer((C.c_ubyte * n).from_address(p), dtype=np.uint8).copy()
+    lib.vr_free(p)
+    return data, (w.value, h.value, d.value, c.value), (sx.value, sy.value, sz.value)
+
+
+def checksum(data: np.ndarray) -> int:
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    return int(load_library().vr_checksum(d.ctypes.data, d.size))
 
 
 def _fp(a: np.ndarray):
