@@ -307,6 +307,15 @@ def extras(args, r, local, stream):
         out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
                      "mpixels_per_s": round(args.width * args.height / ms / 1e3, 1), "kernel": r.last_kernel_name}
 
+    # PCIe-inclusive: kernel + D2H of the finished RGBA32F frame (vr_read_pixels), for DESIGN.md
+    r.setFramebufferExternal(0); r.setFramebufferCompact(False)
+    r.render(); r.readPixels()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        r.renderAsync()
+        r.readPixels()
+    out["frame_plus_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
+    r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
     r.setAlpha(1.0)
     timed("shallow_alpha1_ert")
     r.setAlpha(args.alpha)
