@@ -71,13 +71,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    if os.environ.get("VR_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()      # validation: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        # nccl == RCCL on ROCm.  VR_BENCH_BACKEND=gloo is a validation hook only (several
+        # ranks sharing one GPU, gather staged through host memory).
+        backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     vra = importlib.import_module("volume-renderer_amd")
     from importlib import import_module
@@ -106,10 +114,17 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     r.setStream(stream.cuda_stream)
-    local = torch.zeros((plan.local_rows, W, 4), dtype=torch.float32, device=dev)
+    # Two frame slots: with N > 1 the RCCL all_gather + de-interleave of frame i runs on a
+    # second stream while the kernel of frame i+1 renders into the other slot.
+    nslots = 2 if world > 1 else 1
+    comm_stream = torch.cuda.Stream(dev) if world > 1 else None
+    locals_ = [torch.zeros((plan.local_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)]
+    gathered = [torch.empty((world * plan.local_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
+    ev_rendered = [torch.cuda.Event() for _ in range(nslots)]
+    ev_gathered = [torch.cuda.Event() for _ in range(nslots)]
+    local = locals_[0]
     r.setFramebufferExternal(local.data_ptr())
     r.setFramebufferCompact(True)
-    gathered = torch.empty((world * plan.local_rows, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
     index = torch.as_tensor(sharding.gather_index(plan), device=dev) if world > 1 and plan.mode == "stripes" else None
 
     # ---- untimed: exact sample count of this rank's shard (instrumented kernel)
@@ -124,9 +139,27 @@ def main():
         dist.all_reduce(t)
         total_samples = int(t.item())
 
-    def step():
+    step_no = [0]
+
+    def step(ev_pair=None):
+        slot = step_no[0] % nslots
+        step_no[0] += 1
+        if world > 1:
+            stream.wait_event(ev_gathered[slot])            # slot free again (frame i-2 gathered)
+            r.setFramebufferExternal(locals_[slot].data_ptr())
+        if ev_pair:
+            ev_pair[0].record(stream)
         r.renderAsync()
-        return sharding.gather_frame(local, plan, out=gathered, index=index)
+        if ev_pair:
+            ev_pair[1].record(stream)
+        if world == 1:
+            return locals_[0][:H]
+        ev_rendered[slot].record(stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev_rendered[slot])
+            frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index)
+            ev_gathered[slot].record(comm_stream)
+        return frame
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -142,10 +175,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record(stream)
-        r.renderAsync()
-        ev[i][1].record(stream)
-        frame = sharding.gather_frame(local, plan, out=gathered, index=index)
+        frame = step(ev[i])
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -157,6 +187,23 @@ def main():
     else:
         kernel_ms_max = kernel_ms
     ms_per_step = elapsed * 1e3 / args.steps
+
+    # untimed self-check of the N > 1 path: the gathered frame must equal this rank's own
+    # full-frame render bit for bit
+    gather_ok = None
+    if world > 1:
+        torch.cuda.synchronize(dev)
+        gathered_frame = frame.cpu().numpy()
+        r.setRowRange(0, -1); r.setRowStripes(1, 0, 1)
+        r.setFramebufferExternal(0); r.setFramebufferCompact(False)
+        r.render()
+        full = r.readPixels()
+        gather_ok = bool(np.array_equal(full.view(np.uint32), gathered_frame.view(np.uint32)))
+        sharding.apply_plan(r, plan)
+        r.setFramebufferExternal(locals_[0].data_ptr()); r.setFramebufferCompact(True)
+        t = torch.tensor([1 if gather_ok else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        gather_ok = bool(t.item())
 
     result = None
     if rank == 0:
@@ -200,6 +247,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        if world > 1:
+            result["multi_gpu_frame_bit_exact"] = gather_ok
+            result["overlap"] = "all_gather of frame i on a second stream overlaps the kernel of frame i+1"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
         if world == 1 and args.extras:

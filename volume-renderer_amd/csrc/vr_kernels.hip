@@ -415,8 +415,14 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         return;                                              // padding block
     }
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + (lane & 7u));
-    const int ly = (int)(ty * FAST_TILE_H + (wave >> 2) * 8u + (lane >> 3));
+#ifdef VR_EXP_ZORDER            // experiment: Morton order of the lanes inside the 8x8 wave tile
+    const unsigned mx = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u);
+    const unsigned my = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
+#else
+    const unsigned mx = lane & 7u, my = lane >> 3;
+#endif
+    const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + mx);
+    const int ly = (int)(ty * FAST_TILE_H + (wave >> 2) * 8u + my);
     int px = lx, py;
     if (P.stripe_count > 1) {
         const int s = ly / P.stripe_rows, r = ly % P.stripe_rows;

@@ -94,7 +94,13 @@ def gather_frame(local, plan: RowPlan, out=None, index=None):
         return local[: plan.img_h]
     if out is None:
         out = torch.empty((plan.world * plan.local_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local)
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # validation hook (several ranks sharing one GPU): stage the gather through host memory
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, local)
     if plan.mode == "contiguous":
         return out[: plan.img_h]
     if index is None:
