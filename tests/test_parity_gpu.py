@@ -125,6 +125,7 @@ def test_mip_and_view_swizzles(vra, oracle, mode):
         r.setInitialCameraRotation(top, bottom)
         r.setAlpha(0.6)
         r.render()
+        assert r.last_kernel_name == "raymarch_fast_kernel"      # MIP and the view swizzles have fast variants
         got = r.readPixels()
         _, spp = r.countSamples(per_pixel=True)
     p = oracle.OracleParams(96, 80, alpha_scale=0.6, voxel_size=(1.0, 1.0, 1.3), is_mip=int(mip), view_top=int(top),
@@ -179,7 +180,15 @@ def test_transfer_function(vra, oracle):
         lut = r.getTransferLut()
         r.setAlpha(0.2)
         r.render()
+        assert r.last_kernel_name == "raymarch_fast_kernel"      # LDS-resident RGBA classification table
         got = r.readPixels()
+        r.setKernelVariant(1)
+        r.render()
+        assert np.array_equal(got.view(np.uint32), r.readPixels().view(np.uint32))
+        r.setMIP(True)                                           # MIP + TF has no fast variant
+        r.setKernelVariant(0)
+        r.render()
+        assert r.last_kernel_name == "raymarch_generic_kernel"
     want_lut = oracle.spline_tf(iso, rgba)
     assert np.array_equal(lut.view(np.uint32), want_lut.view(np.uint32))
     want, _ = oracle.render(vol, oracle.OracleParams(90, 70, alpha_scale=0.2, tf_rgba=want_lut))
@@ -464,3 +473,36 @@ def test_cfg4_shape_u8_beyond_4gib_offsets(vra, oracle):
         p.row_begin, p.row_end = y, y + 1
         oracle.render(vol, p, out=want)
         assert_same(got[y], want[y], what=f"cfg4 row {y}")
+
+
+def test_full_size_mip_and_transfer_function_fast_paths(vra, oracle, cfg3):
+    """cfg3-size MIP and TF frames: fast kernel == generic kernel, sparse rows == oracle"""
+    r = cfg3
+    vol = None
+    iso = [0, 141, 149, 255]
+    rgba = [[0, 0, 0, 0], [0.9, 0.4, 0.1, 0.759], [0.2, 0.6, 0.9, 0.45], [1, 1, 1, 1]]
+    for mode in ("mip", "tf"):
+        r.setMIP(mode == "mip")
+        r.setTransferFunction(iso, rgba) if mode == "tf" else r.setTransferFunction()
+        r.setAlpha(0.3 if mode == "mip" else 0.004)
+        if mode == "tf":
+            r.setWindow(0, 2047)                    # 2048-entry RGBA table fits LDS
+        r.render()
+        assert r.last_kernel_name == "raymarch_fast_kernel", mode
+        fast = r.readPixels()
+        r.setKernelVariant(1)
+        r.render()
+        generic = r.readPixels()
+        r.setKernelVariant(0)
+        assert np.array_equal(fast.view(np.uint32), generic.view(np.uint32)), mode
+        if vol is None:
+            vol = r.readVolume()
+        p = oracle.OracleParams(1920, 1080, cam=r.getCameraBlock(), alpha_scale=0.3 if mode == "mip" else 0.004,
+                                min_val=0, max_val=4095 if mode == "mip" else 2047, is_mip=int(mode == "mip"),
+                                tf_rgba=oracle.spline_tf(iso, rgba) if mode == "tf" else None, threads=8)
+        want = np.zeros_like(fast)
+        for y in (300, 540):
+            p.row_begin, p.row_end = y, y + 1
+            oracle.render(vol, p, out=want)
+            assert_same(fast[y], want[y], what=f"cfg3 {mode} row {y}")
+    r.setMIP(False); r.setTransferFunction(); r.setWindow(0, 4095); r.setAlpha(0.004)

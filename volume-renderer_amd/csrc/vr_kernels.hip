@@ -392,9 +392,13 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // fl(q*S + ds*S) == S*fl(q + ds) for a power-of-two S, bit for bit (also in the subnormal
 // range, where fp32 addition is exact), which drops the three per-sample multiplies.
 // NOCLAMP: the dataset's exact min/max lie inside the window, so clamp() is the identity.
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP>
+// MODE: 0 = grey-ramp emission/absorption composite (rayMarchVolume, :104-139)
+//       1 = MIP with the grey ramp (MIP(), :141-173): all four channels carry max(v*alpha)
+//       2 = composite through the 1-D transfer function table (needs LUT; entries are RGBA)
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE>
 __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
+                                                            const float4 *__restrict__ tf,
                                                             const uint32_t vol_bytes,
                                                             float4 *__restrict__ fb,
                                                             uint32_t *__restrict__ spp,
@@ -402,7 +406,8 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const unsigned chunks_per_row,
                                                             const uint32_t *__restrict__ tile_table)
 {
-    __shared__ float2 lut[LUT ? FAST_LUT_MAX : 1];
+    constexpr int LUT_STRIDE = MODE == 2 ? 4 : 2;          // floats per entry
+    __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
 #ifdef VR_EXP_TRACE             // experiment only: per-wave start/end timestamps into spp
     const unsigned long long trace_t0 = wall_clock64();
 #endif
@@ -446,14 +451,24 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
             for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
                 const float v = div_cert(s - P.fmin, P.fden, P.rden);
-                const float a = v * P.alpha_scale;
-                lut[e] = make_float2(v * a, a);
+                if (MODE == 2) {
+                    // classification through the transfer function: index = round(v*(len-1)),
+                    // src.a *= alpha_scale, src.rgb *= src.a
+                    int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
+                    idx = clampi(idx, 0, P.tf_len - 1);
+                    const float4 t = tf[idx];
+                    const float a = t.w * P.alpha_scale;
+                    lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a; lut[4 * e + 3] = a;
+                } else {
+                    const float a = v * P.alpha_scale;
+                    lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
+                }
             }
             __syncthreads();
         }
     }
 
-    float drgb = 0.0f, da = 0.0f;       // grey ramp: r == g == b bit for bit
+    float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f;   // MODE 0/1: r == g == b bit for bit, only drgb is carried
     uint32_t fetches = 0;
     {                                   // every thread runs the (barrier-carrying) batch loop
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)vol_bytes, 0x00020000);
@@ -502,14 +517,22 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
             vj = (int)(tcy * P.fdim[1]);
             vk = (int)(tcz * P.fdim[2]);
         };
-        const int lut_bias = -8 * P.min_val;             // byte offset of entry 0 relative to texel*8
-        // window + grey-ramp classification of one texel -> (c, a) of VolumeRenderer.cs:130-131
-        auto classify = [&](uint32_t texel, float &c, float &a) {
+        constexpr int LUT_SHIFT = MODE == 2 ? 4 : 3;
+        const int lut_bias = -(4 * LUT_STRIDE) * P.min_val;   // byte offset of entry 0 relative to texel*entry_bytes
+        // window + classification of one texel -> premultiplied colour c (cg, cb only in MODE 2)
+        // and opacity a of VolumeRenderer.cs:130-131
+        auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
             if (LUT) {
                 int t = (int)texel;
                 if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);   // clamp(texel, min_val, max_val), min <= max
-                const float2 ca = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lut) + (uint32_t)((t << 3) + lut_bias));
-                c = ca.x; a = ca.y;
+                const char *entry = reinterpret_cast<const char *>(lut) + (uint32_t)((t << LUT_SHIFT) + lut_bias);
+                if (MODE == 2) {
+                    const float4 q = *reinterpret_cast<const float4 *>(entry);
+                    c = q.x; cg = q.y; cb = q.z; a = q.w;
+                } else {
+                    const float2 ca = *reinterpret_cast<const float2 *>(entry);
+                    c = ca.x; a = ca.y;
+                }
             } else {
                 float s = (float)texel;
                 s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
@@ -560,27 +583,34 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         // so "dest.a < 0.95 before the LAST sample" proves the shader's per-sample test
         // `dest.a >= 0.95 -> break` (VolumeRenderer.cs:118) passed for the whole batch; only
         // the batch in which a ray terminates is replayed with the literal per-sample tests.
+        // one sample onto the destination (front-to-back composite, or MIP's running maximum)
+        auto accumulate = [&](float c, float cg, float cb, float a) {
+            if (MODE == 1) {
+                if (da < a) da = a;                          // dest = src when dest.a < src.a (:165-168)
+            } else {
+                const float om = 1.0f - da;
+                drgb += c * om;
+                if (MODE == 2) { dg += cg * om; db += cb * om; }
+                da += a * om;
+            }
+        };
         auto consume = [&](const uint32_t (&v)[FAST_BATCH]) -> bool {
-            float c[FAST_BATCH], a[FAST_BATCH];
+            float c[FAST_BATCH], cg[FAST_BATCH], cb[FAST_BATCH], a[FAST_BATCH];
 #pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) classify(v[u], c[u], a[u]);
-            const float drgb0 = drgb, da0 = da;
+            for (int u = 0; u < FAST_BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
+            const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             float da_last = 0.0f;
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
                 if (u == FAST_BATCH - 1) da_last = da;
-                const float om = 1.0f - da;
-                drgb += c[u] * om;
-                da += a[u] * om;
+                accumulate(c[u], cg[u], cb[u], a[u]);
             }
             if (da_last < 0.95f) { i += FAST_BATCH; return false; }
-            drgb = drgb0; da = da0;
+            drgb = drgb0; dg = dg0; db = db0; da = da0;
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
                 if (da >= 0.95f) return true;
-                const float om = 1.0f - da;
-                drgb += c[u] * om;
-                da += a[u] * om;
+                accumulate(c[u], cg[u], cb[u], a[u]);
                 i++;
             }
             return da >= 0.95f;
@@ -630,11 +660,9 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 const int vi = min((int)(tcx * P.fdim[0]), nxm1);
                 const int vj = min((int)(tcy * P.fdim[1]), nym1);
                 const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-                float c, a;
-                classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, a);
-                const float om = 1.0f - da;
-                drgb += c * om;
-                da += a * om;
+                float c, cg = 0.0f, cb = 0.0f, a;
+                classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, cg, cb, a);
+                accumulate(c, cg, cb, a);
                 qx += dsx; qy += dsy; qz += dsz;
             }
         }
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    fb[pix] = make_float4(drgb, drgb, drgb, da);
+    fb[pix] = MODE == 2 ? make_float4(drgb, dg, db, da) : (MODE == 1 ? make_float4(da, da, da, da) : make_float4(drgb, drgb, drgb, da));
 #ifdef VR_EXP_TRACE
     if (spp && (threadIdx.x & 63u) == 0) {
         const unsigned w = blockIdx.x * 8u + (threadIdx.x >> 6);
@@ -791,59 +819,75 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP>
-static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE>
+static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                               uint32_t *spp, int rows, hipStream_t st)
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP>), dim3(blocks),
-                       dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp,
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE>), dim3(blocks),
+                       dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
                        g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table);
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int VIEW, bool BIG>
-static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
-                                 uint32_t *spp, int rows, hipStream_t st)
+template <typename VoxelT, int LAYOUT, int VIEW, bool BIG, int MODE>
+static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                                 float4 *fb, uint32_t *spp, int rows, hipStream_t st)
 {
-    const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
+    // the no-clamp specialisation is kept for the headline mode only (compile time)
+    const bool lut = L.use_lut != 0, noclamp = MODE == 0 && lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+#define VR_LAUNCH(TC, LT, P2, NC) launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE>(P, L, vol, tf, fb, spp, rows, st)
     if (L.divmode_tc == DIV_CERT) {
-        if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, true, false, true>(P, L, vol, fb, spp, rows, st)
-                                : launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, true, false, false>(P, L, vol, fb, spp, rows, st);
-        return launch_fast<VoxelT, LAYOUT, DIV_CERT, VIEW, BIG, false, false, false>(P, L, vol, fb, spp, rows, st);
+        if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
+        if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
+        return hipErrorInvalidValue;
     }
     if (pow2) {
-        if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, true, true>(P, L, vol, fb, spp, rows, st)
-                                : launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, true, false>(P, L, vol, fb, spp, rows, st);
-        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, false, true, false>(P, L, vol, fb, spp, rows, st);
+        if (lut) return noclamp ? VR_LAUNCH(DIV_UNIT, true, true, true) : VR_LAUNCH(DIV_UNIT, true, true, false);
+        if (MODE != 2) return VR_LAUNCH(DIV_UNIT, false, true, false);
+        return hipErrorInvalidValue;
     }
-    if (lut) return noclamp ? launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, false, true>(P, L, vol, fb, spp, rows, st)
-                            : launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, true, false, false>(P, L, vol, fb, spp, rows, st);
-    return launch_fast<VoxelT, LAYOUT, DIV_UNIT, VIEW, BIG, false, false, false>(P, L, vol, fb, spp, rows, st);
+    if (lut) return noclamp ? VR_LAUNCH(DIV_UNIT, true, false, true) : VR_LAUNCH(DIV_UNIT, true, false, false);
+    if (MODE != 2) return VR_LAUNCH(DIV_UNIT, false, false, false);
+    return hipErrorInvalidValue;
+#undef VR_LAUNCH
+}
+
+template <typename VoxelT, int LAYOUT, int VIEW, bool BIG>
+static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                                 float4 *fb, uint32_t *spp, int rows, hipStream_t st)
+{
+    if (L.mip) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 1>(P, L, vol, tf, fb, spp, rows, st);
+    if (P.tf_len > 1) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 2>(P, L, vol, tf, fb, spp, rows, st);
+    return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 0>(P, L, vol, tf, fb, spp, rows, st);
 }
 
 template <typename VoxelT, int LAYOUT>
-static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb,
-                                uint32_t *spp, int rows, hipStream_t st)
+static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                                float4 *fb, uint32_t *spp, int rows, hipStream_t st)
 {
     const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
     if (L.big_offsets) {
-        if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, true>(P, L, vol, fb, spp, rows, st);
-        if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, true>(P, L, vol, fb, spp, rows, st);
-        return dispatch_fast2<VoxelT, LAYOUT, 2, true>(P, L, vol, fb, spp, rows, st);
+        if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, true>(P, L, vol, tf, fb, spp, rows, st);
+        if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, true>(P, L, vol, tf, fb, spp, rows, st);
+        return dispatch_fast2<VoxelT, LAYOUT, 2, true>(P, L, vol, tf, fb, spp, rows, st);
     }
-    if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, false>(P, L, vol, fb, spp, rows, st);
-    if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, false>(P, L, vol, fb, spp, rows, st);
-    return dispatch_fast2<VoxelT, LAYOUT, 2, false>(P, L, vol, fb, spp, rows, st);
+    if (view == 0) return dispatch_fast2<VoxelT, LAYOUT, 0, false>(P, L, vol, tf, fb, spp, rows, st);
+    if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, false>(P, L, vol, tf, fb, spp, rows, st);
+    return dispatch_fast2<VoxelT, LAYOUT, 2, false>(P, L, vol, tf, fb, spp, rows, st);
 }
 
-// The specialised kernel covers NEAREST / composite / iterative / grey ramp with a
-// non-degenerate window whose divisions were certified; everything else is generic.
+// The specialised kernel covers NEAREST + iterative accumulation with a non-degenerate
+// window whose divisions were certified and alpha_scale in [0,1]: grey-ramp composite,
+// grey-ramp MIP, and composite through a transfer-function table that fits LDS.
+// Everything else (TRILINEAR, closed-form accumulation, MIP + TF, ...) is generic.
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
 {
-    return !L.generic && L.filter == 0 && L.mip == 0 && P.accum == 0 && P.tf_len <= 1 && P.fden > 0.0f &&
+    const bool tf = P.tf_len > 1;
+    if (tf && (L.mip || !L.use_lut)) return false;
+    return !L.generic && L.filter == 0 && P.accum == 0 && P.fden > 0.0f &&
            P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT &&
            P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f;
 }
@@ -872,7 +916,7 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     if (kernel_name) *kernel_name = fast ? "raymarch_fast_kernel" : "raymarch_generic_kernel";
 #define VR_GO(T, LAY)                                                                                        \
     do {                                                                                                      \
-        if (fast) return dispatch_fast<T, LAY>(P, L, vol, fb, spp, rows, st);                                 \
+        if (fast) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);                                 \
         return count ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)             \
                      : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);           \
     } while (0)
