@@ -506,3 +506,74 @@ def test_full_size_mip_and_transfer_function_fast_paths(vra, oracle, cfg3):
             oracle.render(vol, p, out=want)
             assert_same(fast[y], want[y], what=f"cfg3 {mode} row {y}")
     r.setMIP(False); r.setTransferFunction(); r.setWindow(0, 4095); r.setAlpha(0.004)
+
+
+# ---------------------------------------------------------------------------------------
+# exact empty-space skipping (config 4's "adaptive step"): never changes a bit
+# ---------------------------------------------------------------------------------------
+def test_skip_empty_is_bit_exact_small(vra, oracle):
+    vol8 = oracle.gen_sphere_u8(96, 30)                 # a ball in a sea of zeros
+    vol16 = oracle.gen_noise_ball((80, 96, 72), 2, 7)   # noise 0..63 outside the ball
+    iso = [0, 60, 149, 255]
+    rgba = [[0, 0, 0, 0], [0.0, 0.0, 0.0, 0.0], [0.8, 0.2, 0.4, 0.45], [1, 1, 1, 1]]
+    cases = [
+        ("u8 grey", vol8, dict(min_val=0, max_val=255), dict()),
+        ("u8 window", vol8, dict(min_val=40, max_val=200), dict()),
+        ("u16 window", vol16, dict(min_val=64, max_val=4095), dict()),
+        ("u16 mip", vol16, dict(min_val=64, max_val=4095, is_mip=1), dict(mip=True)),
+        ("u8 tf", vol8, dict(min_val=0, max_val=255), dict(tf=True)),
+        ("u8 aniso (skipping must disable itself)", vol8, dict(min_val=0, max_val=255, voxel_size=(1.0, 1.0, 4.0)), dict()),
+    ]
+    for name, vol, okw, opt in cases:
+        with make_renderer(vra, (150, 110)) as r:
+            r.setQuirks(0)
+            r.setLayout(vra.renderer.LAYOUT_BRICKED)
+            r.setVolume(vol, okw.get("voxel_size", (1.0, 1.0, 1.0)))
+            r.setWindow(okw["min_val"], okw["max_val"])
+            r.setMIP(opt.get("mip", False))
+            if opt.get("tf"):
+                r.setTransferFunction(iso, rgba)
+            r.setAlpha(0.3)
+            for cname, block in orbit_blocks(oracle)[:4]:
+                r.setCameraBlock(block)
+                r.setSkipEmpty(False)
+                r.render()
+                assert r.last_kernel_name == "raymarch_fast_kernel", name
+                plain = r.readPixels()
+                r.setSkipEmpty(True)
+                r.render()
+                skipped = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                assert np.array_equal(plain.view(np.uint32), skipped.view(np.uint32)), (name, cname)
+                p = oracle.OracleParams(150, 110, cam=block, alpha_scale=0.3, **okw)
+                if opt.get("tf"):
+                    p.tf_rgba = oracle.spline_tf(iso, rgba)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                assert_same(skipped, want, spp, want_spp, what=f"skip {name} {cname}")
+
+
+def test_skip_empty_full_size_windowed(vra, oracle, cfg3):
+    """cfg3 volume with the window raised above the background noise: everything outside the
+    ball classifies to zero and is skipped; the frame must not change by a bit"""
+    r = cfg3
+    r.setWindow(64, 4095)
+    r.setAlpha(0.004)
+    r.setSkipEmpty(False)
+    r.render(); r.kernelMsTake()
+    for _ in range(5):
+        r.render()
+    t_plain = r.kernelMsTake() / 5
+    plain = r.readPixels()
+    r.setSkipEmpty(True)
+    r.render(); r.kernelMsTake()
+    for _ in range(5):
+        r.render()
+    t_skip = r.kernelMsTake() / 5
+    skipped = r.readPixels()
+    total = r.countSamples()
+    r.setSkipEmpty(False)
+    r.setWindow(0, 4095)
+    assert np.array_equal(plain.view(np.uint32), skipped.view(np.uint32))
+    assert total == 480301374                       # logical samples are unchanged
+    print(f"cfg3 window [64,4095]: {t_plain:.3f} ms without, {t_skip:.3f} ms with empty-space skipping")
+    assert t_skip < t_plain

@@ -176,6 +176,7 @@ size_t RendererCore::storageVoxels(int nx, int ny, int nz, int lay) const
 void RendererCore::freeVolume()
 {
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
+    if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
 }
 
 void RendererCore::allocVolume(int nx, int ny, int nz, int bytes, int lay)
@@ -571,8 +572,71 @@ void RendererCore::launch(uint32_t *spp)
     FrameParams P;
     LaunchConfig L;
     buildFrame(P, L);
+    refreshSkipGrid(P, L);
     refreshTileSchedule(P, L);
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
+}
+
+// Exact empty-space skipping (vr_set_skip_empty): the fast kernel may skip a batch of
+// samples only if every voxel it could touch classifies to (0,0,0,0), so compositing it
+// cannot change dest.  "Classifies to zero" is a prefix of the window: voxel <= min_val maps
+// to v = 0 (grey ramp / MIP); with a transfer function the prefix is as long as its leading
+// zero-opacity entries.  The grid holds, per 8^3-voxel cell, the maximum over the cell and
+// its 26 neighbours.
+void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
+{
+    L.skip_grid = nullptr;
+    L.skip_grid_bytes = 0;
+    P.skip_empty = 0;
+    if (!skip_empty || !fast_path_eligible(P, L)) return;
+    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    // a batch of 8 samples must stay within +-1 cell of its middle sample: bound the voxel
+    // advance per step on every voxel axis (|dir| <= 1)
+    float max_delta = 0.0f;
+    const bool swz = (u_.view_bottom == 1 || u_.view_top == 1);
+    const float vdim[3] = {(float)nx, swz ? (float)nz : (float)ny, swz ? (float)ny : (float)nz};   // voxel axis behind each box axis
+    for (int a = 0; a < 3; a++) max_delta = std::max(max_delta, P.step * vdim[a] / P.ext[a]);
+    if (!(4.0f * max_delta + 0.6f <= 8.0f)) return;
+    // threshold: largest voxel value whose classification is exactly zero
+    int thresh;
+    if (P.alpha_scale == 0.0f) {
+        thresh = 65535;
+    } else if (tf_lut_.empty()) {
+        thresh = u_.min_val;                             // v = (clamp(t) - min)/den = 0  <=>  t <= min_val
+    } else {
+        int e = 0;
+        const int width = u_.max_val - u_.min_val;
+        for (; e <= width; e++) {
+            const float s = (float)(u_.min_val + e);
+            const float v = (s - P.fmin) / P.fden;       // == the kernel's certified quotient
+            int idx = (int)std::floor(v * 255.0f + 0.5f);
+            idx = std::min(std::max(idx, 0), 255);
+            if (tf_lut_[4 * idx + 3] * P.alpha_scale != 0.0f) break;
+        }
+        thresh = u_.min_val + e - 1;                     // e == 0: even the lowest entry is visible
+        if (e == 0) return;
+    }
+    const uint32_t cnx = (uint32_t)(nx + 7) / 8, cny = (uint32_t)(ny + 7) / 8, cnz = (uint32_t)(nz + 7) / 8;
+    const size_t cells = (size_t)cnx * cny * cnz;
+    if (cells * 2 >= (1ull << 32) || cnx >= (1u << 24) || (uint64_t)cny * cnz >= (1u << 24)) return;
+    if (!d_skip_grid_) {
+        uint16_t *tmp = nullptr;
+        check(hipMalloc(reinterpret_cast<void **>(&tmp), cells * sizeof(uint16_t)), "hipMalloc(skip grid tmp)");
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_skip_grid_), cells * sizeof(uint16_t));
+        if (e == hipSuccess)
+            e = launch_build_skip_grid(d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, vol_layout_,
+                                       (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), tmp, d_skip_grid_, stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(stream());
+        (void)hipFree(tmp);
+        if (e != hipSuccess && d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; }
+        check(e, "build skip grid");
+        skip_grid_cells_ = cells;
+    }
+    P.skip_empty = 1;
+    P.skip_thresh = thresh;
+    P.cnx = (int32_t)cnx; P.cny = (int32_t)cny; P.cnz = (int32_t)cnz;
+    L.skip_grid = d_skip_grid_;
+    L.skip_grid_bytes = (uint32_t)(cells * sizeof(uint16_t));
 }
 
 // Rebuild the longest-first block order when the camera / image / shard changed.  The
@@ -610,7 +674,7 @@ void RendererCore::render()
     // on its result (src/RendererCore.cpp:149-153); same shape with HIP events
     FrameParams P;   // certify (may sync) before the timed region
     LaunchConfig L;
-    if (cs_program_ && d_vol_) { buildFrame(P, L); refreshTileSchedule(P, L); }
+    if (cs_program_ && d_vol_) { buildFrame(P, L); refreshSkipGrid(P, L); refreshTileSchedule(P, L); }
     check(hipEventRecord(ev0_, stream()), "hipEventRecord");
     launch(nullptr);
     check(hipEventRecord(ev1_, stream()), "hipEventRecord");

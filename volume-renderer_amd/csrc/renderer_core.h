@@ -120,6 +120,9 @@ private:
     int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;
     bool fb_compact_ = false;
     std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
+    uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
+    size_t skip_grid_cells_ = 0;
+    void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
     uint64_t tile_table_key_ = 0;

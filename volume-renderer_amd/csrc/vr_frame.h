@@ -31,7 +31,9 @@ struct FrameParams {
     int32_t max_steps;             // 10000
     int32_t accum;                 // VR_ACCUM_*
     int32_t tf_len;                // 0 = grey ramp
-    int32_t skip_empty;
+    int32_t skip_empty;            // exact empty-space skipping on the dilated cell-max grid
+    int32_t skip_thresh;           // a cell is empty when its (dilated) max voxel <= skip_thresh
+    int32_t cnx, cny, cnz;         // cells (8x8x8 voxels) per axis
     // bricked layout (VR_LAYOUT_BRICKED): bricks of 4x4x4 voxels, x-fastest inside
     int32_t bnx, bny, bnz;         // bricks per axis
     uint32_t bstride_y, bstride_z; // 64*bnx - 16 and 64*bnx*bny - 64 (see VoxelAddr)
@@ -50,6 +52,8 @@ struct LaunchConfig {
     int lut_noclamp;               // exact dataset range lies inside the window
     int pow2_dims;                 // nx, ny, nz are powers of two
     uint32_t vol_bytes32;          // volume allocation size for the buffer descriptor (!big)
+    const uint16_t *skip_grid;     // device: dilated per-cell max (nullptr = no skipping)
+    uint32_t skip_grid_bytes;
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;
 };

@@ -18,6 +18,11 @@ int launch_local_rows(const FrameParams &P);
 hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                            float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name);
 
+// dilated per-cell (8^3 voxels) maximum for exact empty-space skipping; tmp/out hold
+// ceil(nx/8)*ceil(ny/8)*ceil(nz/8) uint16 each
+hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
+                                  uint32_t bnx, uint32_t bny, uint16_t *tmp, uint16_t *out, hipStream_t st);
+
 // *d_bad must be zeroed by the caller; non-zero afterwards = divisor not certified
 hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st);
 

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             uint32_t *__restrict__ spp,
                                                             const unsigned tiles_x, const unsigned tiles_y,
                                                             const unsigned chunks_per_row,
-                                                            const uint32_t *__restrict__ tile_table)
+                                                            const uint32_t *__restrict__ tile_table,
+                                                            const uint16_t *__restrict__ skip_grid,
+                                                            const uint32_t skip_grid_bytes)
 {
     constexpr int LUT_STRIDE = MODE == 2 ? 4 : 2;          // floats per entry
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
@@ -546,8 +548,57 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
         const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
         const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
-        // gathers of one batch: FAST_BATCH consecutive samples from the current position
-        auto issue = [&](uint32_t (&v)[FAST_BATCH]) {
+        // ---- exact empty-space skipping (vr_set_skip_empty): a batch is skipped when the
+        // dilated cell-max grid says every voxel within one 8^3 cell of the batch's middle
+        // sample classifies to (0,0,0,0), i.e. compositing it cannot change a single bit of
+        // dest.  The grid is probed one batch ahead at an APPROXIMATE position (closed form
+        // V0 + k*dV in voxel units; the 3x3x3 dilation covers the +-4.5 voxels of the batch
+        // and the approximation error), so the probe never delays the gathers.
+        const bool skip_on = P.skip_empty != 0 && skip_grid != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_grid = __builtin_amdgcn_make_buffer_rsrc((void *)skip_grid, 0, (int)skip_grid_bytes, 0x00020000);
+        float V0x = 0.0f, V0y = 0.0f, V0z = 0.0f, dVx = 0.0f, dVy = 0.0f, dVz = 0.0f;
+        if (skip_on) {
+            // affine map position -> voxel coordinate per voxel axis (flips included)
+            auto to_voxel = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
+                const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
+                const float uz = 1.0f - (az + P.half[2]) * P.rext[2];
+                float tcx = ux, tcy = uy, tcz = uz;
+                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+                fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
+            };
+            float ex, ey, ez;
+            to_voxel(qx, qy, qz, V0x, V0y, V0z);
+            to_voxel(qx + dsx, qy + dsy, qz + dsz, ex, ey, ez);
+            dVx = ex - V0x; dVy = ey - V0y; dVz = ez - V0z;
+        }
+        // probe for the batch whose first sample has index k0
+        auto probe = [&](int k0) -> uint32_t {
+            const float km = (float)k0 + 0.5f * (float)(FAST_BATCH - 1);
+            int ci = (int)(V0x + km * dVx) >> 3, cj = (int)(V0y + km * dVy) >> 3, ck = (int)(V0z + km * dVz) >> 3;
+            ci = min(max(ci, 0), P.cnx - 1); cj = min(max(cj, 0), P.cny - 1); ck = min(max(ck, 0), P.cnz - 1);
+            const uint32_t cell = mad_u24(mad_u24((uint32_t)ck, (uint32_t)P.cny, (uint32_t)cj), (uint32_t)P.cnx, (uint32_t)ci);
+            return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs_grid, (int)(cell << 1), 0, 0);
+        };
+        uint32_t cell_next = 0xffffffffu;       // probe result for the next batch to be issued
+        int k_issue = 0;                        // index of the first sample of the next batch to be issued
+        // gathers of one batch: FAST_BATCH consecutive samples from the current position;
+        // returns true when the batch is skipped (positions still advance, bit-exactly)
+        auto issue = [&](uint32_t (&v)[FAST_BATCH]) -> bool {
+            bool skip = false;
+            if (skip_on) {
+                skip = (int)cell_next <= P.skip_thresh;
+                cell_next = probe(k_issue + FAST_BATCH);
+                k_issue += FAST_BATCH;
+            }
+            if (skip) {
+#pragma unroll
+                for (int u = 0; u < FAST_BATCH; u++) {
+                    if (POW2) { Qx += dSx; Qy += dSy; Qz += dSz; }
+                    else { qx += dsx; qy += dsy; qz += dsz; }
+                }
+                return true;
+            }
             typename VoxelAddr<LAYOUT, BIG>::type off[FAST_BATCH];
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
@@ -576,6 +627,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
 #endif
             }
+            return false;
         };
         int i = 0;
         // front-to-back compositing of one batch; returns true when the ray terminated.
@@ -594,7 +646,8 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 da += a * om;
             }
         };
-        auto consume = [&](const uint32_t (&v)[FAST_BATCH]) -> bool {
+        auto consume = [&](const uint32_t (&v)[FAST_BATCH], bool skipped) -> bool {
+            if (skipped) { i += FAST_BATCH; return false; }   // every sample of the batch adds exactly zero
             float c[FAST_BATCH], cg[FAST_BATCH], cb[FAST_BATCH], a[FAST_BATCH];
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
@@ -625,19 +678,23 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
             uint32_t va[FAST_BATCH], vb[FAST_BATCH];
+            bool skip_a = false, skip_b = false;
             int b = 0;
             bool fin = nb == 0;
-            if (!fin) issue(va);
+            if (!fin) {
+                if (skip_on) cell_next = probe(0);
+                skip_a = issue(va);
+            }
             for (;;) {
                 if (__syncthreads_and(fin ? 1 : 0)) break;
                 if (!fin) {
-                    if (b + 1 < nb) issue(vb);
-                    if (consume(va)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_b = issue(vb);
+                    if (consume(va, skip_a)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
                 if (!fin) {
-                    if (b + 1 < nb) issue(va);
-                    if (consume(vb)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_a = issue(va);
+                    if (consume(vb, skip_b)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
             }
@@ -800,6 +857,48 @@ __global__ __launch_bounds__(256) void stats_kernel(const VoxelT *__restrict__ v
     }
 }
 
+// per-cell (8x8x8 voxels) maximum, then its 3x3x3 dilation: the grid the fast kernel probes
+// for exact empty-space skipping
+template <typename VoxelT>
+__global__ __launch_bounds__(256) void cellmax_kernel(const VoxelT *__restrict__ vol, uint16_t *__restrict__ out, uint32_t nx,
+                                                      uint32_t ny, uint32_t nz, int layout, uint32_t bnx, uint32_t bny,
+                                                      uint32_t cnx, uint32_t cny, uint32_t cnz)
+{
+    // one wavefront per cell: 64 lanes x 8 voxels
+    const uint64_t cell = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (cell >= (uint64_t)cnx * cny * cnz) return;
+    const uint32_t ci = (uint32_t)(cell % cnx), cj = (uint32_t)((cell / cnx) % cny), ck = (uint32_t)(cell / ((uint64_t)cnx * cny));
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned m = 0;
+    for (unsigned t = lane; t < 512u; t += 64u) {
+        const uint32_t i = ci * 8u + (t & 7u), j = cj * 8u + ((t >> 3) & 7u), k = ck * 8u + (t >> 6);
+        if (i < nx && j < ny && k < nz) {
+            const unsigned v = vol[storage_index(layout, i, j, k, nx, ny, bnx, bny)];
+            m = v > m ? v : m;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) out[cell] = (uint16_t)m;
+}
+
+__global__ __launch_bounds__(256) void dilate_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int cnx,
+                                                     int cny, int cnz)
+{
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= (int64_t)cnx * cny * cnz) return;
+    const int ci = (int)(cell % cnx), cj = (int)((cell / cnx) % cny), ck = (int)(cell / ((int64_t)cnx * cny));
+    unsigned m = 0;
+    for (int dk = -1; dk <= 1; dk++)
+        for (int dj = -1; dj <= 1; dj++)
+            for (int di = -1; di <= 1; di++) {
+                const int i = ci + di, j = cj + dj, k = ck + dk;
+                if (i < 0 || j < 0 || k < 0 || i >= cnx || j >= cny || k >= cnz) continue;
+                const unsigned v = in[(int64_t)i + (int64_t)cnx * ((int64_t)j + (int64_t)cny * k)];
+                m = v > m ? v : m;
+            }
+    out[cell] = (uint16_t)m;
+}
+
 // ------------------------------------------------------------------ launchers
 static inline unsigned padded_blocks(unsigned tiles_x, unsigned tiles_y)
 {
@@ -827,7 +926,7 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
     hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
-                       g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table);
+                       g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes);
     return hipGetLastError();
 }
 
@@ -926,6 +1025,22 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
         if (L.layout == 0) VR_GO(uint16_t, 0); else VR_GO(uint16_t, 1);
     }
 #undef VR_GO
+}
+
+hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
+                                  uint32_t bnx, uint32_t bny, uint16_t *tmp, uint16_t *out, hipStream_t st)
+{
+    const uint32_t cnx = (nx + 7) / 8, cny = (ny + 7) / 8, cnz = (nz + 7) / 8;
+    const uint64_t cells = (uint64_t)cnx * cny * cnz;
+    const unsigned blocks_a = (unsigned)((cells + 3) / 4), blocks_b = (unsigned)((cells + 255) / 256);
+    if (bytes_per_voxel == 1)
+        hipLaunchKernelGGL(cellmax_kernel<uint8_t>, dim3(blocks_a), dim3(256), 0, st, (const uint8_t *)vol, tmp, nx, ny, nz,
+                           layout, bnx, bny, cnx, cny, cnz);
+    else
+        hipLaunchKernelGGL(cellmax_kernel<uint16_t>, dim3(blocks_a), dim3(256), 0, st, (const uint16_t *)vol, tmp, nx, ny, nz,
+                           layout, bnx, bny, cnx, cny, cnz);
+    hipLaunchKernelGGL(dilate_kernel, dim3(blocks_b), dim3(256), 0, st, tmp, out, (int)cnx, (int)cny, (int)cnz);
+    return hipGetLastError();
 }
 
 hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st)
