@@ -577,3 +577,60 @@ def test_skip_empty_full_size_windowed(vra, oracle, cfg3):
     assert total == 480301374                       # logical samples are unchanged
     print(f"cfg3 window [64,4095]: {t_plain:.3f} ms without, {t_skip:.3f} ms with empty-space skipping")
     assert t_skip < t_plain
+
+
+def _random_camera_block(rng, radius_lo=0.2, radius_hi=4.0):
+    """random eye + orthonormal basis looking roughly at the box (also from inside / grazing)"""
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    eye = d * rng.uniform(radius_lo, radius_hi)
+    target = rng.uniform(-0.45, 0.45, size=3)
+    look = target - eye; look /= np.linalg.norm(look)
+    up0 = rng.normal(size=3)
+    side = np.cross(look, up0); side /= np.linalg.norm(side)
+    up = np.cross(side, look)
+    b = np.zeros(21, dtype=np.float32)
+    b[0:3] = side; b[4:7] = up; b[8:11] = -look; b[12:15] = eye; b[15] = 1
+    b[16:19] = eye; b[19] = 1
+    b[20] = rng.uniform(1.0, 5.0)          # view_plane_dist (FOV 22..90 degrees)
+    return b
+
+
+def test_randomised_cameras_volumes_and_modes(vra, oracle):
+    """stress of the safe-prefix / certified-division / batching logic: random dims (odd,
+    tiny, power-of-two), spacings, cameras (inside, grazing, axis-parallel), windows, alpha"""
+    rng = np.random.default_rng(20260928)
+    dims_pool = [(1, 1, 1), (2, 3, 5), (8, 8, 8), (16, 32, 64), (31, 17, 9), (64, 64, 64), (50, 1, 50), (128, 4, 4)]
+    n_checked = 0
+    for trial in range(120):
+        dims = dims_pool[trial % len(dims_pool)]
+        dtype = np.uint8 if trial % 3 else np.uint16
+        vol = rand_volume(rng, dims, dtype, smooth=bool(trial % 2))
+        spacing = (1.0, 1.0, 1.0) if trial % 4 == 0 else tuple(np.round(rng.uniform(0.3, 2.5, size=3), 3).tolist())
+        vmax = 255 if dtype == np.uint8 else 4095
+        lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
+        alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
+        W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
+        with make_renderer(vra, (W, H)) as r:
+            r.setQuirks(0)
+            r.setLayout(trial % 2)
+            r.setVolume(vol, spacing)
+            r.setWindow(lo, hi)
+            r.setAlpha(alpha)
+            r.setSkipEmpty(bool(trial % 5 == 0))
+            top, bottom = (trial % 7 == 3), (trial % 7 == 5)
+            if top or bottom:
+                r.setInitialCameraRotation(top, bottom)
+            for _ in range(3):
+                block = _random_camera_block(rng)
+                if rng.random() < 0.25:                       # axis-parallel rays (zero direction components)
+                    block = oracle.default_camera_block(); block[16:19] = block[12:15] = (rng.uniform(-0.4, 0.4), 0.0, 3.0)
+                r.setCameraBlock(block)
+                r.render()
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi,
+                                        view_top=int(top), view_bottom=int(bottom))
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                assert_same(got, want, spp, want_spp, what=f"trial {trial} dims {dims} spacing {spacing} kernel {r.last_kernel_name}")
+                n_checked += 1
+    assert n_checked == 360

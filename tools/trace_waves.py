@@ -10,7 +10,7 @@ r.setLayout(1 if layout == "bricked" else 0)
 r.generateSynthetic(R.SYNTH_NOISE_BALL, (1024,)*3, 2, 0x9E3779B9); r.setWindow(0, 4095); r.setAlpha(0.004)
 for _ in range(3): r.render()
 _, spp = r.countSamples(per_pixel=True)
-t = spp.ravel()[: 34560 * 4].reshape(-1, 4)
+t = spp.ravel()[: 32768 * 4].reshape(-1, 4)
 ok = t[:, 1] != 0
 t = t[ok]
 t0 = t[:, 0].astype(np.int64); t1 = t[:, 1].astype(np.int64)

@@ -395,7 +395,9 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // MODE: 0 = grey-ramp emission/absorption composite (rayMarchVolume, :104-139)
 //       1 = MIP with the grey ramp (MIP(), :141-173): all four channels carry max(v*alpha)
 //       2 = composite through the 1-D transfer function table (needs LUT; entries are RGBA)
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE>
+// SKIPT: empty-space skipping compiled in (its probe state costs ~18 VGPRs = one workgroup
+// of occupancy per CU, so the headline variant is also built without it).
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT>
 __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const float4 *__restrict__ tf,
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         // dest.  The grid is probed one batch ahead at an APPROXIMATE position (closed form
         // V0 + k*dV in voxel units; the 3x3x3 dilation covers the +-4.5 voxels of the batch
         // and the approximation error), so the probe never delays the gathers.
-        const bool skip_on = P.skip_empty != 0 && skip_grid != nullptr;
+        const bool skip_on = SKIPT && P.skip_empty != 0 && skip_grid != nullptr;
         const __amdgpu_buffer_rsrc_t rs_grid = __builtin_amdgcn_make_buffer_rsrc((void *)skip_grid, 0, (int)skip_grid_bytes, 0x00020000);
         float V0x = 0.0f, V0y = 0.0f, V0z = 0.0f, dVx = 0.0f, dVy = 0.0f, dVz = 0.0f;
         if (skip_on) {
@@ -649,10 +651,15 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         auto consume = [&](const uint32_t (&v)[FAST_BATCH], bool skipped) -> bool {
             if (skipped) { i += FAST_BATCH; return false; }   // every sample of the batch adds exactly zero
             float c[FAST_BATCH], cg[FAST_BATCH], cb[FAST_BATCH], a[FAST_BATCH];
-#pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             float da_last = 0.0f;
+            // table look-ups in two halves: half the live registers, the second half's LDS
+            // latency hides behind the first half's dependent compositing chain
+            constexpr int HALF = FAST_BATCH / 2;
+#pragma unroll
+            for (int u = 0; u < HALF; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
+#pragma unroll
+            for (int u = HALF; u < FAST_BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
 #pragma unroll
             for (int u = 0; u < FAST_BATCH; u++) {
                 if (u == FAST_BATCH - 1) da_last = da;
@@ -699,7 +706,13 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 }
             }
         }
-        if (POW2) { qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz; }   // exact: S is a power of two
+        // back to box units for the tail (exact: S is a power of two); the step is re-derived
+        // from its scaled copy so that only one of the two is live across the batch loop
+        float tsx = dsx, tsy = dsy, tsz = dsz;
+        if (POW2) {
+            qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz;
+            tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
+        }
         // ---- checked tail: the shader's loop, literally (dest.a > 0.99 of :134 is implied
         //      by the dest.a >= 0.95 test of the next iteration and changes nothing)
         if (hit && !done) {
@@ -720,7 +733,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 float c, cg = 0.0f, cb = 0.0f, a;
                 classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, cg, cb, a);
                 accumulate(c, cg, cb, a);
-                qx += dsx; qy += dsy; qz += dsz;
+                qx += tsx; qy += tsy; qz += tsz;
             }
         }
         fetches = (uint32_t)i;
@@ -918,13 +931,13 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT>
 static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                               uint32_t *spp, int rows, hipStream_t st)
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE>), dim3(blocks),
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
                        g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes);
     return hipGetLastError();
@@ -937,7 +950,12 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     // the no-clamp specialisation is kept for the headline mode only (compile time)
     const bool lut = L.use_lut != 0, noclamp = MODE == 0 && lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-#define VR_LAUNCH(TC, LT, P2, NC) launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE>(P, L, vol, tf, fb, spp, rows, st)
+    // the skipping-free build exists for the headline shape only (MODE 0, default view)
+    constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
+    const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
+#define VR_LAUNCH(TC, LT, P2, NC)                                                                                         \
+    (noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE>(P, L, vol, tf, fb, spp, rows, st) \
+            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true>(P, L, vol, tf, fb, spp, rows, st))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
         if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
