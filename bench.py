@@ -42,7 +42,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--volume", type=int, default=1024, help="synthetic volume edge (voxels)")
+    ap.add_argument("--dims", type=int, nargs=3, default=None, help="non-cubic synthetic volume NX NY NZ (overrides --volume)")
     ap.add_argument("--bytes", type=int, default=2, choices=(1, 2))
+    ap.add_argument("--skip-empty", action="store_true", help="exact empty-space skipping (config 4)")
+    ap.add_argument("--window", type=int, nargs=2, default=None, help="min max (default: full range of the generator)")
+    ap.add_argument("--tf", action="store_true", help="default alpha-spline transfer function (config 4)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--alpha", type=float, default=0.004)
@@ -100,8 +104,13 @@ def main():
     r.loadShader("VolumeRenderer.cs")
     r.setQuirks(0)   # explicit window below is what the kernel sees (no +1000, no truncated grid)
     r.setLayout(R.LAYOUT_BRICKED if args.layout == "bricked" else R.LAYOUT_LINEAR)
-    r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
-    r.setWindow(0, vmax)
+    dims = tuple(args.dims) if args.dims else (N, N, N)
+    r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
+    win = tuple(args.window) if args.window else (0, vmax)
+    r.setWindow(*win)
+    if args.tf:   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59), black->white ramp
+        r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
+    r.setSkipEmpty(args.skip_empty)
     r.setAlpha(args.alpha)
     r.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
     if args.pose == "offaxis":
@@ -227,10 +236,11 @@ def main():
             "dtype": "f32 compositing over u%d voxels" % (8 * b),
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic noise-ball {N}^3 uint{8 * b} (generated in HBM, seed 0x9E3779B9), "
+                "workload": f"synthetic noise-ball {'x'.join(map(str, dims))} uint{8 * b} (generated in HBM, seed 0x9E3779B9), "
                             f"{W}x{H} RGBA32F, reference default camera" + (" (off-axis pose)" if args.pose != "default" else "")
-                            + f", {args.filter.upper()} filter, window [0,{vmax}], alpha_scale {args.alpha}, "
-                            f"iterative accumulation, {args.layout} layout",
+                            + f", {args.filter.upper()} filter, window [{win[0]},{win[1]}], alpha_scale {args.alpha}, "
+                            + ("transfer function, " if args.tf else "") + ("empty-space skipping, " if args.skip_empty else "")
+                            + f"iterative accumulation, {args.layout} layout",
                 "samples_per_frame": total_samples,
                 "partition": "single GPU" if world == 1 else f"{args.partition} rows x{world}"
                              + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
@@ -276,6 +286,8 @@ def load_traffic(args, world):
         return None
     try:
         d = json.loads(p.read_text())
+        if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default":
+            return None
         key = f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
         return d.get(key)
     except Exception:
@@ -290,13 +302,15 @@ def cpu_baseline(args, r, frame, gpu_msamples):
 
     W, H, b = args.width, args.height, args.bytes
     vmax = 4095 if b == 2 else 255
+    win = tuple(args.window) if args.window else (0, vmax)
     vol = r.readVolume()
     cam = r.getCameraBlock()
+    tf = r.getTransferLut() if args.tf else None
     gpu = frame.cpu().numpy()
 
     def run(rows, threads):
-        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=0, max_val=vmax,
-                                filter=1 if args.filter == "trilinear" else 0, threads=threads)
+        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1],
+                                filter=1 if args.filter == "trilinear" else 0, threads=threads, tf_rgba=tf)
         out = np.zeros((H, W, 4), dtype=np.float32)
         samples, secs = 0, 0.0
         for y in rows:
@@ -313,7 +327,7 @@ def cpu_baseline(args, r, frame, gpu_msamples):
     rate = ps / max(pt, 1e-9)
     stride = args.cpu_row_stride
     if stride <= 0:
-        est_full = 4.8e8 * (args.volume / 1024.0) * (W * H) / (1920 * 1080) / max(rate, 1.0)
+        est_full = 4.8e8 * (max(vol.shape) / 1024.0) * (W * H) / (1920 * 1080) / max(rate, 1.0)
         stride = max(1, int(np.ceil(est_full / 15.0)))
     rows = list(range(stride // 2, H, stride))
     out, samples, secs = run(rows, 1)
