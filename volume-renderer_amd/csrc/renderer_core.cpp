@@ -651,7 +651,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     const uint64_t key = tileScheduleKey(P, rows);
     if (key != tile_table_key_ || !d_tile_table_) {
         std::vector<uint32_t> table;
-        buildTileSchedule(P, rows, table);
+        tile_active_ = buildTileSchedule(P, rows, table);
         if (table.size() > tile_table_capacity_) {
             if (d_tile_table_) { check(hipFree(d_tile_table_), "hipFree(tile table)"); d_tile_table_ = nullptr; }
             check(hipMalloc(reinterpret_cast<void **>(&d_tile_table_), table.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
@@ -665,6 +665,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
+    // 8 wavefronts per active tile against 256 CUs x 32 wave slots
+    L.sparse_shard = (tile_active_ * 8u < 2048u) ? 1 : 0;
 }
 
 void RendererCore::render()

@@ -59,8 +59,9 @@ uint64_t tileScheduleKey(const FrameParams &P, int rows)
     return hsh;
 }
 
-void buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table)
 {
+    unsigned active_tiles = 0;
     const unsigned tiles_x = (unsigned)((P.img_w + (int)kFastTileW - 1) / (int)kFastTileW);
     const unsigned tiles_y = (unsigned)((rows + (int)kFastTileH - 1) / (int)kFastTileH);
     const unsigned cpr = (tiles_x + kFastChunk - 1) / kFastChunk;
@@ -85,6 +86,7 @@ void buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &ta
                         wmax = std::max(wmax, raySamples(P, px, py));
                     }
                 work += wmax;
+                if (wmax > 0.0) active_tiles++;
             }
             chunks.push_back({work, cx, ty});
         }
@@ -103,6 +105,7 @@ void buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &ta
             table[b] = tx | (chunks[r].ty << 16);
         }
     }
+    return active_tiles;
 }
 
 }  // namespace vr

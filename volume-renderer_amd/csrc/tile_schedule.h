@@ -19,7 +19,8 @@ constexpr uint32_t kTilePadding = 0xffffffffu;
 
 // table[b] = tile_x | tile_y << 16 for block b, kTilePadding for padding blocks.
 // `rows` = local image rows of this launch (stripe padding included).
-void buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table);
+// returns the number of tiles with a non-zero work estimate
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table);
 
 // cheap fingerprint of everything the schedule depends on
 uint64_t tileScheduleKey(const FrameParams &P, int rows);

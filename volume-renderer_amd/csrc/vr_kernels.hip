@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 // on |pos|; both are linear in k, so a sample range is safe iff its two end points
 // lie inside the box shrunk by that error plus a fixed 16-ulp margin.
 //
-// The prefix is marched in batches of FAST_BATCH samples: positions do not depend on
-// the voxel data, so the batch's FAST_BATCH gathers are issued back to back (memory-
+// The prefix is marched in batches of BATCH samples: positions do not depend on
+// the voxel data, so the batch's BATCH gathers are issued back to back (memory-
 // level parallelism: the loop is latency-bound otherwise) and composited in order
 // afterwards, with the shader's early-termination tests between samples.  Gathers
 // past an early termination are speculative reads inside the volume; they change
@@ -295,10 +295,6 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 //   e -> (c, a) = (v*a, v*alpha_scale),  v = (float(min_val+e) - min_val)/(max_val-min_val)
 // for e in [0, max_val-min_val] in LDS with the shader's own operations (so entries are
 // bit-identical to the per-sample computation) and a sample then costs one ds_read_b64.
-#ifndef VR_FAST_BATCH
-#define VR_FAST_BATCH 8
-#endif
-constexpr int FAST_BATCH = VR_FAST_BATCH;
 constexpr int FAST_LUT_MAX = 4096;      // entries (x 8 B = 32 KiB of the CU's 160 KiB LDS)
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c)
@@ -397,7 +393,9 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 //       2 = composite through the 1-D transfer function table (needs LUT; entries are RGBA)
 // SKIPT: empty-space skipping compiled in (its probe state costs ~18 VGPRs = one workgroup
 // of occupancy per CU, so the headline variant is also built without it).
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT>
+// BATCH: samples per gather batch (8; 16 for shards that leave most wave slots empty, where
+// a lone wavefront needs more loads in flight -- skipping's dilation covers 8 only).
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
 __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const float4 *__restrict__ tf,
@@ -410,6 +408,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const uint16_t *__restrict__ skip_grid,
                                                             const uint32_t skip_grid_bytes)
 {
+    static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
     constexpr int LUT_STRIDE = MODE == 2 ? 4 : 2;          // floats per entry
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
 #ifdef VR_EXP_TRACE             // experiment only: per-wave start/end timestamps into spp
@@ -576,7 +575,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         }
         // probe for the batch whose first sample has index k0
         auto probe = [&](int k0) -> uint32_t {
-            const float km = (float)k0 + 0.5f * (float)(FAST_BATCH - 1);
+            const float km = (float)k0 + 0.5f * (float)(BATCH - 1);
             int ci = (int)(V0x + km * dVx) >> 3, cj = (int)(V0y + km * dVy) >> 3, ck = (int)(V0z + km * dVz) >> 3;
             ci = min(max(ci, 0), P.cnx - 1); cj = min(max(cj, 0), P.cny - 1); ck = min(max(ck, 0), P.cnz - 1);
             const uint32_t cell = mad_u24(mad_u24((uint32_t)ck, (uint32_t)P.cny, (uint32_t)cj), (uint32_t)P.cnx, (uint32_t)ci);
@@ -584,26 +583,26 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         };
         uint32_t cell_next = 0xffffffffu;       // probe result for the next batch to be issued
         int k_issue = 0;                        // index of the first sample of the next batch to be issued
-        // gathers of one batch: FAST_BATCH consecutive samples from the current position;
+        // gathers of one batch: BATCH consecutive samples from the current position;
         // returns true when the batch is skipped (positions still advance, bit-exactly)
-        auto issue = [&](uint32_t (&v)[FAST_BATCH]) -> bool {
+        auto issue = [&](uint32_t (&v)[BATCH]) -> bool {
             bool skip = false;
             if (skip_on) {
                 skip = (int)cell_next <= P.skip_thresh;
-                cell_next = probe(k_issue + FAST_BATCH);
-                k_issue += FAST_BATCH;
+                cell_next = probe(k_issue + BATCH);
+                k_issue += BATCH;
             }
             if (skip) {
 #pragma unroll
-                for (int u = 0; u < FAST_BATCH; u++) {
+                for (int u = 0; u < BATCH; u++) {
                     if (POW2) { Qx += dSx; Qy += dSy; Qz += dSz; }
                     else { qx += dsx; qy += dsy; qz += dsz; }
                 }
                 return true;
             }
-            typename VoxelAddr<LAYOUT, BIG>::type off[FAST_BATCH];
+            typename VoxelAddr<LAYOUT, BIG>::type off[BATCH];
 #pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) {
+            for (int u = 0; u < BATCH; u++) {
                 int vi, vj, vk;
                 if (POW2) {
                     // voxel units: Q = q*S, U = Q + half*S = texcoord*S before the flips
@@ -620,7 +619,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
             }
 #pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) {
+            for (int u = 0; u < BATCH; u++) {
 #if defined(VR_EXP_NOLOAD)      // experiment only: no memory access at all (VALU bound)
                 v[u] = (uint32_t)(off[u] & 4095u);
 #elif defined(VR_EXP_MASK)      // experiment only: fold all accesses into 1 MiB (cache-resident)
@@ -648,27 +647,27 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                 da += a * om;
             }
         };
-        auto consume = [&](const uint32_t (&v)[FAST_BATCH], bool skipped) -> bool {
-            if (skipped) { i += FAST_BATCH; return false; }   // every sample of the batch adds exactly zero
-            float c[FAST_BATCH], cg[FAST_BATCH], cb[FAST_BATCH], a[FAST_BATCH];
+        auto consume = [&](const uint32_t (&v)[BATCH], bool skipped) -> bool {
+            if (skipped) { i += BATCH; return false; }   // every sample of the batch adds exactly zero
+            float c[BATCH], cg[BATCH], cb[BATCH], a[BATCH];
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             float da_last = 0.0f;
             // table look-ups in two halves: half the live registers, the second half's LDS
             // latency hides behind the first half's dependent compositing chain
-            constexpr int HALF = FAST_BATCH / 2;
+            constexpr int HALF = BATCH / 2;
 #pragma unroll
             for (int u = 0; u < HALF; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
 #pragma unroll
-            for (int u = HALF; u < FAST_BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
+            for (int u = HALF; u < BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
 #pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) {
-                if (u == FAST_BATCH - 1) da_last = da;
+            for (int u = 0; u < BATCH; u++) {
+                if (u == BATCH - 1) da_last = da;
                 accumulate(c[u], cg[u], cb[u], a[u]);
             }
-            if (da_last < 0.95f) { i += FAST_BATCH; return false; }
+            if (da_last < 0.95f) { i += BATCH; return false; }
             drgb = drgb0; dg = dg0; db = db0; da = da0;
 #pragma unroll
-            for (int u = 0; u < FAST_BATCH; u++) {
+            for (int u = 0; u < BATCH; u++) {
                 if (da >= 0.95f) return true;
                 accumulate(c[u], cg[u], cb[u], a[u]);
                 i++;
@@ -679,12 +678,12 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         bool done = false;
         // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
         //      while the current batch is composited
-        const int nb = k_safe / FAST_BATCH;
+        const int nb = k_safe / BATCH;
         // The 8 wavefronts of a workgroup advance in lockstep (one barrier per two batches):
         // their rays cross the same voxel rows / bricks at the same time, so a cache line
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
-            uint32_t va[FAST_BATCH], vb[FAST_BATCH];
+            uint32_t va[BATCH], vb[BATCH];
             bool skip_a = false, skip_b = false;
             int b = 0;
             bool fin = nb == 0;
@@ -931,13 +930,13 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
 static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                               uint32_t *spp, int rows, hipStream_t st)
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT>), dim3(blocks),
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
                        g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes);
     return hipGetLastError();
@@ -954,8 +953,9 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
 #define VR_LAUNCH(TC, LT, P2, NC)                                                                                         \
-    (noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE>(P, L, vol, tf, fb, spp, rows, st) \
-            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true>(P, L, vol, tf, fb, spp, rows, st))
+    (noskip ? (L.sparse_shard ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, HEADLINE ? 16 : 8>(P, L, vol, tf, fb, spp, rows, st)  \
+                              : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8>(P, L, vol, tf, fb, spp, rows, st))                 \
+            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true, 8>(P, L, vol, tf, fb, spp, rows, st))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
         if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
