@@ -634,3 +634,45 @@ def test_randomised_cameras_volumes_and_modes(vra, oracle):
                 assert_same(got, want, spp, want_spp, what=f"trial {trial} dims {dims} spacing {spacing} kernel {r.last_kernel_name}")
                 n_checked += 1
     assert n_checked == 360
+
+
+def test_out_of_contract_parameters_fall_back_to_the_generic_kernel(vra, oracle):
+    """reversed window (min > max), alpha_scale outside [0,1], negative window bounds:
+    legal shader inputs with odd semantics -- the generic kernel repeats them literally"""
+    rng = np.random.default_rng(41)
+    vol = rand_volume(rng, (30, 26, 34), np.uint8)
+    cases = [
+        dict(min_val=200, max_val=50, alpha_scale=0.01),      # clamp(x,lo,hi) with lo > hi -> hi, not normalised
+        dict(min_val=0, max_val=255, alpha_scale=1.7),        # dest.a can overshoot and oscillate
+        dict(min_val=0, max_val=255, alpha_scale=-0.3),
+        dict(min_val=-40, max_val=300, alpha_scale=0.2),      # window wider than the data type
+    ]
+    for kw in cases:
+        with make_renderer(vra, (72, 60)) as r:
+            r.setVolume(vol)
+            r.setWindow(kw["min_val"], kw["max_val"])
+            r.setAlpha(kw["alpha_scale"])
+            r.render()
+            got = r.readPixels()
+            _, spp = r.countSamples(per_pixel=True)
+            kernel = r.last_kernel_name
+        want, _, want_spp = oracle.render(vol, oracle.OracleParams(72, 60, **kw), want_spp=True)
+        assert_same(got, want, spp, want_spp, what=f"{kw} via {kernel}")
+        if kw["min_val"] > kw["max_val"] or not (0.0 <= kw["alpha_scale"] <= 1.0):
+            assert kernel == "raymarch_generic_kernel"
+
+
+def test_mip_and_tf_deep_regime_timings_are_reported(vra, cfg3):
+    """not a performance gate: prints the fast-path timings of the non-headline modes"""
+    r = cfg3
+    out = {}
+    for name, setup in (("composite", lambda: None), ("mip", lambda: r.setMIP(True)),
+                        ("tf", lambda: (r.setWindow(0, 2047), r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [.5, .5, .5, .759], [.6, .6, .6, .45], [1, 1, 1, 1]])))):
+        setup()
+        r.render(); r.kernelMsTake()
+        for _ in range(5):
+            r.render()
+        out[name] = (round(r.kernelMsTake() / 5, 3), r.last_kernel_name)
+        r.setMIP(False); r.setTransferFunction(); r.setWindow(0, 4095)
+    print("cfg3 deep regime:", out)
+    assert all(k == "raymarch_fast_kernel" for _, k in out.values())
