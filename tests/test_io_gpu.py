@@ -1,0 +1,143 @@
+"""GPU tests of the rows either side of the ray-march: RAW/.inf and PVM files
+through readVolumeData onto the device, default window / histogram, screenshots, caller-owned
+targets and streams."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def make(vra, size):
+    r = vra.RendererCore(0)
+    r.setup(size)
+    assert r.loadShader("VolumeRenderer.cs")
+    return r
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+def test_raw_file_roundtrip_and_render(vra, oracle, tmp_path, dtype):
+    rng = np.random.default_rng(3)
+    dims = (21, 34, 13)
+    hi = 256 if dtype == np.uint8 else 3000
+    vol = rng.integers(0, hi, size=(dims[2], dims[1], dims[0])).astype(dtype)
+    raw = tmp_path / "scan.raw"
+    raw.write_bytes(vol.tobytes())
+    (tmp_path / "scan.raw.inf").write_text("#dimensions\n21 34 13\n\n#voxel-spacing\n1 0.9 1.4\n")
+    with make(vra, (90, 70)) as r:
+        r.readVolumeData(raw, vol.dtype.itemsize)
+        assert r.takeMessage() == ("File Loaded!", "File Loaded Successfully!")
+        assert r.loaded_dataset == "scan.raw"
+        d, s, b = r.dims
+        assert d == dims and b == vol.dtype.itemsize and s == pytest.approx((1.0, 0.9, 1.4))
+        assert np.array_equal(r.readVolume(), vol)
+        lo, hi_ = (0, 255) if dtype == np.uint8 else (int(vol.min()), int(vol.max()))
+        assert r.window == (lo, hi_) and r.dataset_range == (lo, hi_)      # RendererCore.cpp:360-384
+        r.setAlpha(0.1)
+        r.render()
+        got = r.readPixels()
+        block = r.getCameraBlock()
+    off = 1000 if dtype == np.uint16 else 0                                 # Q10 is on by default
+    p = oracle.OracleParams(90, 70, cam=block, alpha_scale=0.1, voxel_size=(1.0, 0.9, 1.4), min_val=lo + off, max_val=hi_ + off)
+    want, _ = oracle.render(vol, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_pvm_file_to_device_and_render(vra, oracle):
+    cases = {c["file"]: c for c in json.loads((GOLDEN / "pvm_manifest.json").read_text())}
+    c = cases["pvm2_u16_8x6x4_scaled.pvm"]
+    payload = np.load(GOLDEN / c["payload"])
+    with make(vra, (64, 48)) as r:
+        r.readVolumeData(GOLDEN / c["file"], 2)
+        d, s, b = r.dims
+        assert d == (8, 6, 4) and b == 2 and s == pytest.approx((1.0, 0.5, 2.0))
+        # Q9: the big-endian 16-bit payload is reinterpreted in host order, no swap
+        vol = payload.view("<u2").reshape(4, 6, 8)
+        assert np.array_equal(r.readVolume(), vol)
+        r.setQuirks(0)
+        r.setWindow(int(vol.min()), int(vol.max()))
+        r.render()
+        got = r.readPixels()
+        block = r.getCameraBlock()
+        # an 8-bit PVM, and the component/datasize mismatch the reference would read out of bounds on
+        c8 = cases["pvm3_u8_10x10x3_desc.pvm"]
+        r.readVolumeData(GOLDEN / c8["file"], 1)
+        assert np.array_equal(r.readVolume().ravel(), np.load(GOLDEN / c8["payload"]))
+        with pytest.raises(vra.VRError):
+            r.readVolumeData(GOLDEN / c8["file"], 2)
+        assert r.takeMessage() == ("Error!", "Error reading PVM file")
+    p = oracle.OracleParams(64, 48, cam=block, voxel_size=(1.0, 0.5, 2.0), min_val=int(vol.min()), max_val=int(vol.max()))
+    want, _ = oracle.render(vol, p)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_histogram_u16_matches_reference_formula(vra):
+    rng = np.random.default_rng(8)
+    vol = rng.integers(5, 3000, size=(18, 22, 26)).astype(np.uint16)
+    with make(vra, (32, 32)) as r:
+        r.setVolume(vol)
+        h = r.histogram()
+        mx = r.dataset_range[1]
+    # val = round(val * 255.0f / max_dataset_val) as uint16; bin 0 skipped; normaliser starts at max_dataset_val
+    bins = np.round(vol.astype(np.float32) * np.float32(255.0) / np.float32(mx)).astype(np.int64).ravel()
+    counts = np.bincount(bins, minlength=256).astype(np.float64)[:256]
+    counts[0] = 0
+    norm = max(float(mx), counts.max())
+    want = (counts.astype(np.float32) * np.float32(100.0) / np.float32(norm)).astype(np.float32)
+    assert np.allclose(h, want, rtol=1e-6)
+
+
+def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
+    from PIL import Image
+
+    vol = oracle.gen_sphere_u8(48, 20)
+    with make(vra, (77, 52)) as r:       # odd width: row stride not a multiple of 4
+        r.setVolume(vol)
+        r.setAlpha(0.5)
+        r.render()
+        frame = r.readPixels()
+        for ext in (".png", ".bmp", ".ppm"):
+            assert r.saveImage(tmp_path / f"shot{ext}", ext)
+        assert not r.saveImage(tmp_path / "shot.jpg", ".jpg")
+    want = np.floor(np.clip(frame[::-1, :, :3], 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)   # top row first
+    for ext in (".png", ".bmp", ".ppm"):
+        img = np.asarray(Image.open(tmp_path / f"shot{ext}").convert("RGB"))
+        assert img.shape == (52, 77, 3) and np.array_equal(img, want), ext
+
+
+def test_external_target_stream_and_compact_shard(vra, oracle):
+    import torch
+
+    vol = oracle.gen_noise_ball((40, 40, 40), 1, 5)
+    W, H = 96, 64
+    with make(vra, (W, H)) as r:
+        r.setVolume(vol)
+        r.setAlpha(0.05)
+        r.render()
+        full = r.readPixels()
+        stream = torch.cuda.Stream()
+        r.setStream(stream.cuda_stream)
+        tgt = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        r.setFramebufferExternal(tgt.data_ptr())
+        assert r.framebufferDevice() == tgt.data_ptr()
+        r.renderAsync()
+        stream.synchronize()
+        assert np.array_equal(tgt.cpu().numpy().view(np.uint32), full.view(np.uint32))
+        # compact shard: rows 16..47 land at local rows 0..31 of a 32-row target
+        part = torch.zeros((32, W, 4), dtype=torch.float32, device="cuda")
+        r.setFramebufferExternal(part.data_ptr())
+        r.setFramebufferCompact(True)
+        r.setRowRange(16, 48)
+        assert r.localRows() == 32
+        r.renderAsync()
+        r.synchronize()
+        assert np.array_equal(part.cpu().numpy().view(np.uint32), full[16:48].view(np.uint32))
+        r.setStream(0)
+        r.setFramebufferExternal(0)
+        r.setFramebufferCompact(False)
+        r.setRowRange(0, -1)
+        r.render()
+        assert np.array_equal(r.readPixels().view(np.uint32), full.view(np.uint32))

@@ -67,6 +67,14 @@ def load_library() -> C.CDLL:
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or make -C volume-renderer_amd). There is no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  If this process is going to use
+    # torch as well (bench.py, RCCL), torch's copy must be the first one loaded: libvr_core.so
+    # then binds to it by soname and the process has ONE runtime.  The other order leaves torch
+    # unable to see the device.  (Plain C/C++ clients of the library do not involve torch.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     h = C.c_void_p
     f32, i32, u32, u64 = C.c_float, C.c_int, C.c_uint32, C.c_uint64
