@@ -11,6 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+FAST_KERNELS = ("raymarch_fast_kernel", "raymarch_relay_kernel")   # relay = sparse launches of the headline shape
 
 
 def make_renderer(vra, size, **kw):
@@ -65,7 +66,7 @@ def test_cfg0_sphere_default_camera(vra, oracle):
         r.render()
         got = r.readPixels()
         total, spp = r.countSamples(per_pixel=True)
-        assert r.last_kernel_name == "raymarch_fast_kernel"
+        assert r.last_kernel_name in FAST_KERNELS
         assert r.kernelMsTake() > 0.0
     want, want_total, want_spp = oracle.render(vol, oracle.OracleParams(256, 256), want_spp=True)
     assert total == want_total
@@ -125,7 +126,7 @@ def test_mip_and_view_swizzles(vra, oracle, mode):
         r.setInitialCameraRotation(top, bottom)
         r.setAlpha(0.6)
         r.render()
-        assert r.last_kernel_name == "raymarch_fast_kernel"      # MIP and the view swizzles have fast variants
+        assert r.last_kernel_name in FAST_KERNELS      # MIP and the view swizzles have fast variants
         got = r.readPixels()
         _, spp = r.countSamples(per_pixel=True)
     p = oracle.OracleParams(96, 80, alpha_scale=0.6, voxel_size=(1.0, 1.0, 1.3), is_mip=int(mip), view_top=int(top),
@@ -180,7 +181,7 @@ def test_transfer_function(vra, oracle):
         lut = r.getTransferLut()
         r.setAlpha(0.2)
         r.render()
-        assert r.last_kernel_name == "raymarch_fast_kernel"      # LDS-resident RGBA classification table
+        assert r.last_kernel_name in FAST_KERNELS      # LDS-resident RGBA classification table
         got = r.readPixels()
         r.setKernelVariant(1)
         r.render()
@@ -361,7 +362,7 @@ def cfg3(vra):
 def test_cfg3_full_size_fast_equals_generic_and_layouts_agree(vra, cfg3):
     r = cfg3
     r.render()
-    assert r.last_kernel_name == "raymarch_fast_kernel"
+    assert r.last_kernel_name in FAST_KERNELS
     fast = r.readPixels()
     total = r.countSamples()
     assert total == 480301374                     # S of BASELINE.md section 2 (4.803e8)
@@ -437,7 +438,7 @@ def test_cfg2_shape_u16_window_ert_nonpow2(vra, oracle):
         assert r.window == (lo, hi)
         r.setAlpha(0.05)
         r.render()
-        assert r.last_kernel_name == "raymarch_fast_kernel"
+        assert r.last_kernel_name in FAST_KERNELS
         got = r.readPixels()
         _, spp = r.countSamples(per_pixel=True)
         vol = r.readVolume()
@@ -459,7 +460,7 @@ def test_cfg4_shape_u8_beyond_4gib_offsets(vra, oracle):
         r.generateSynthetic(vra.renderer.SYNTH_NOISE_BALL, dims, 1, 99)
         r.setAlpha(0.002)
         r.render()
-        assert r.last_kernel_name == "raymarch_fast_kernel"
+        assert r.last_kernel_name in FAST_KERNELS
         got = r.readPixels()
         r.setKernelVariant(1)
         r.render()
@@ -488,7 +489,7 @@ def test_full_size_mip_and_transfer_function_fast_paths(vra, oracle, cfg3):
         if mode == "tf":
             r.setWindow(0, 2047)                    # 2048-entry RGBA table fits LDS
         r.render()
-        assert r.last_kernel_name == "raymarch_fast_kernel", mode
+        assert r.last_kernel_name in FAST_KERNELS, mode
         fast = r.readPixels()
         r.setKernelVariant(1)
         r.render()
@@ -538,7 +539,7 @@ def test_skip_empty_is_bit_exact_small(vra, oracle):
                 r.setCameraBlock(block)
                 r.setSkipEmpty(False)
                 r.render()
-                assert r.last_kernel_name == "raymarch_fast_kernel", name
+                assert r.last_kernel_name in FAST_KERNELS, name
                 plain = r.readPixels()
                 r.setSkipEmpty(True)
                 r.render()
@@ -675,4 +676,56 @@ def test_mip_and_tf_deep_regime_timings_are_reported(vra, cfg3):
         out[name] = (round(r.kernelMsTake() / 5, 3), r.last_kernel_name)
         r.setMIP(False); r.setTransferFunction(); r.setWindow(0, 4095)
     print("cfg3 deep regime:", out)
-    assert all(k == "raymarch_fast_kernel" for _, k in out.values())
+    assert all(k in FAST_KERNELS for _, k in out.values())
+
+
+@pytest.mark.parametrize("variant", [2, 3], ids=["dense-variants", "relay"])
+def test_relay_kernel_equals_fast_kernel(vra, oracle, variant):
+    """the 4-wavefront relay (sparse launches) against the oracle, forced on and off, across
+    dtypes / layouts / window (LUT, no-LUT, clamp) / early termination / cameras"""
+    rng = np.random.default_rng(77)
+    for dims, dtype, win, alpha in [((64, 64, 64), np.uint8, (0, 255), 0.02), ((64, 64, 64), np.uint8, (30, 190), 1.0),
+                                    ((40, 56, 24), np.uint16, (0, 4095), 0.05), ((128, 64, 32), np.uint16, (100, 60000), 0.3),
+                                    ((33, 31, 65), np.uint8, (0, 255), 0.0)]:
+        vol = rand_volume(rng, dims, dtype, smooth=True)
+        for layout in (0, 1):
+            with make_renderer(vra, (120, 88)) as r:
+                r.setQuirks(0)
+                r.setLayout(layout)
+                r.setKernelVariant(variant)
+                r.setVolume(vol, (1.0, 1.0, 1.0) if dims[0] == dims[1] == dims[2] else (1.0, 0.7, 1.9))
+                r.setWindow(*win)
+                r.setAlpha(alpha)
+                for name, block in orbit_blocks(oracle):
+                    r.setCameraBlock(block)
+                    r.render()
+                    assert r.last_kernel_name == ("raymarch_relay_kernel" if variant == 3 else "raymarch_fast_kernel")
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    p = oracle.OracleParams(120, 88, cam=block, alpha_scale=alpha, min_val=win[0], max_val=win[1],
+                                            voxel_size=(1.0, 1.0, 1.0) if dims[0] == dims[1] == dims[2] else (1.0, 0.7, 1.9))
+                    want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                    assert_same(got, want, spp, want_spp, what=f"variant {variant} {dims} {dtype.__name__} layout {layout} {name}")
+
+
+def test_relay_kernel_full_size_shard(vra, cfg3):
+    """one rank's stripes of the cfg3 frame at N = 8: relay kernel == fast kernel, bit for bit"""
+    r = cfg3
+    r.setRowStripes(16, 5, 8)
+    r.setKernelVariant(2)
+    r.render(); r.kernelMsTake()
+    for _ in range(5):
+        r.render()
+    t_fast = r.kernelMsTake() / 5
+    assert r.last_kernel_name == "raymarch_fast_kernel"
+    fast = r.readPixels()
+    r.setKernelVariant(0)
+    r.render(); r.kernelMsTake()
+    for _ in range(5):
+        r.render()
+    t_relay = r.kernelMsTake() / 5
+    assert r.last_kernel_name == "raymarch_relay_kernel"      # chosen automatically for this sparse shard
+    relay = r.readPixels()
+    r.setRowStripes(1, 0, 1)
+    assert np.array_equal(fast.view(np.uint32), relay.view(np.uint32))
+    print(f"cfg3 shard 5/8: fast kernel {t_fast:.3f} ms, relay kernel {t_relay:.3f} ms")

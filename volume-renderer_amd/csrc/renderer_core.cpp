@@ -533,7 +533,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.filter = filter;
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
-    L.generic = force_generic;
+    L.generic = force_generic == 1 ? 1 : 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
         const uint64_t bsy = 64ull * (uint64_t)P.bnx - 16ull, bsz = 64ull * (uint64_t)P.bnx * (uint64_t)P.bny - 64ull;
@@ -665,8 +665,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
-    // 8 wavefronts per active tile against 256 CUs x 32 wave slots
-    L.sparse_shard = (tile_active_ * 8u < 2048u) ? 1 : 0;
+    // 8 wavefronts per active 32x16 tile against 256 CUs x 32 wave slots: a launch that cannot
+    // fill the chip once is latency-bound per ray -> relay kernel (measured crossover: N = 2 shards)
+    L.sparse_shard = (tile_active_ * 8u < 8192u) ? 1 : 0;
+    if (force_generic == 2) L.sparse_shard = 0;          // kernel variant 2: never the relay / 16-sample variants
+    if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
 }
 
 void RendererCore::render()

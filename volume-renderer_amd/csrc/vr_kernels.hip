@@ -352,6 +352,36 @@ struct VoxelFetch {
     }
 };
 
+// Number of leading samples of a ray whose texcoords are provably inside (0,1)^3 (see the
+// fast kernel's header): q = first sample position, ds = per-sample step, box units.
+__device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx, float qy, float qz, float dsx,
+                                                  float dsy, float dsz)
+{
+    // B bounds |pos| for every sample that is still inside the box
+    const float hm = fmaxf(fmaxf(P.half[0], P.half[1]), P.half[2]);
+    const float B = hm + fmaxf(fmaxf(fabsf(dsx), fabsf(dsy)), fabsf(dsz)) + 1e-3f;
+    const float e = B * 1.1920929e-7f;          // 2 * 2^-24 * B per step
+    const float base = hm * 9.5367432e-7f;      // 16 * 2^-24 * hm fixed margin
+    float kmax = (float)P.max_steps;
+    bool ok = true;
+    const float q[3] = { qx, qy, qz }, ds[3] = { dsx, dsy, dsz };
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lim = P.half[a] - base;     // shrunk half extent
+        // position after k steps must satisfy  q + k*ds + k*e <= lim  and  q + k*ds - k*e >= -lim
+        ok = ok && (q[a] <= lim) && (q[a] >= -lim) && (lim > 0.0f);
+        const float up = ds[a] + e;             // > 0: upper face approached
+        const float dn = ds[a] - e;             // < 0: lower face approached
+        if (up > 0.0f) kmax = fminf(kmax, (lim - q[a]) / up);
+        if (dn < 0.0f) kmax = fminf(kmax, (-lim - q[a]) / dn);
+    }
+    int k_safe = 0;
+    if (ok && kmax > 4.0f) k_safe = (int)(kmax * 0.999f) - 2;
+    if (!(k_safe > 0)) k_safe = 0;
+    if (k_safe > P.max_steps) k_safe = P.max_steps;
+    return k_safe;
+}
+
 // Workgroup = 512 threads = 8 wavefronts = a 32x16-pixel tile (4x2 wave tiles of 8x8).
 // Blocks are handed to XCDs in chunks of FAST_CHUNK horizontally adjacent tiles; with an
 // odd number of chunks per tile row the owner (chunk index mod 8) rotates from row to row,
@@ -393,8 +423,7 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 //       2 = composite through the 1-D transfer function table (needs LUT; entries are RGBA)
 // SKIPT: empty-space skipping compiled in (its probe state costs ~18 VGPRs = one workgroup
 // of occupancy per CU, so the headline variant is also built without it).
-// BATCH: samples per gather batch (8; 16 for shards that leave most wave slots empty, where
-// a lone wavefront needs more loads in flight -- skipping's dilation covers 8 only).
+// BATCH: samples per gather batch (8: the skip grid's dilation covers exactly that).
 template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
 __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
@@ -481,31 +510,7 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
         const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
 
         // ---- safe prefix length
-        int k_safe = 0;
-        {
-            // B bounds |pos| for every sample that is still inside the box
-            const float hm = fmaxf(fmaxf(P.half[0], P.half[1]), P.half[2]);
-            const float B = hm + fmaxf(fmaxf(fabsf(dsx), fabsf(dsy)), fabsf(dsz)) + 1e-3f;
-            const float e = B * 1.1920929e-7f;          // 2 * 2^-24 * B per step
-            const float base = hm * 9.5367432e-7f;      // 16 * 2^-24 * hm fixed margin
-            float kmax = (float)P.max_steps;
-            bool ok = true;
-            const float q[3] = { qx, qy, qz }, ds[3] = { dsx, dsy, dsz };
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const float lim = P.half[a] - base;     // shrunk half extent
-                // position after k steps must satisfy  q + k*ds + k*e <= lim  and  q + k*ds - k*e >= -lim
-                ok = ok && (q[a] <= lim) && (q[a] >= -lim) && (lim > 0.0f);
-                const float up = ds[a] + e;             // > 0: upper face approached
-                const float dn = ds[a] - e;             // < 0: lower face approached
-                if (up > 0.0f) kmax = fminf(kmax, (lim - q[a]) / up);
-                if (dn < 0.0f) kmax = fminf(kmax, (-lim - q[a]) / dn);
-            }
-            if (ok && kmax > 4.0f) k_safe = (int)(kmax * 0.999f) - 2;
-            if (!(k_safe > 0)) k_safe = 0;
-            if (k_safe > P.max_steps) k_safe = P.max_steps;
-            if (!hit) k_safe = 0;
-        }
+        const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
 
         // texcoord -> voxel index of a position; valid (unclamped) inside the prefix
         auto voxel_of = [&](float ax, float ay, float az, int &vi, int &vj, int &vk) {
@@ -753,6 +758,238 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
 #endif
 }
 
+// ------------------------------------------------------------------ relay kernel
+// Strong-scaling variant for launches that do not fill the chip's 8192 wave slots (one GPU's
+// shard of a 2..8-GPU frame: at N = 8 it is ~1300 ray tiles).  There a ray is a serial chain
+// of ~1000 dependent samples issued by ONE wavefront at ~300 cycles per sample, so a shard
+// costs >= 0.16 ms however idle the chip is.  Here FOUR wavefronts march one 8x8-pixel tile
+// as a relay: wavefront w owns batches w, w+4, w+8, ...; for its batch it generates the
+// addresses, gathers and classifies on its own, and only the front-to-back compositing
+// recurrence is handed from wavefront to wavefront through LDS (state = dest colour, dest
+// alpha, sample count per ray; one sequence word published with release/acquire at
+// workgroup scope).  Every sample still goes through exactly the shader's operations in
+// the shader's order; only WHICH wavefront executes them changes.
+// Same preconditions as the fast kernel's headline shape (NEAREST, grey-ramp composite,
+// iterative accumulation, default view, 32-bit offsets, alpha_scale in [0,1]).
+constexpr int RELAY_WAVES = 4, RELAY_BATCH = 8;   // batches of 16 measured the same, 32 spills
+
+struct RelayState {
+    float rgb[2][64];
+    float a[2][64];
+    int i[2][64];
+    unsigned seq;          // number of batches composited so far
+};
+
+template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP>
+__global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P,
+                                                             const VoxelT *__restrict__ vol,
+                                                             const uint32_t vol_bytes,
+                                                             float4 *__restrict__ fb,
+                                                             uint32_t *__restrict__ spp,
+                                                             const uint32_t *__restrict__ tile_table)
+{
+    __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];
+    __shared__ RelayState rs;
+    // block b -> (32x16 tile of the longest-first table, 8x8 sub-tile); the 8 sub-tiles of a
+    // tile are consecutive blocks of ONE XCD (b & 7 is the XCD)
+    const unsigned b = blockIdx.x;
+    const uint32_t tile = tile_table[(b >> 6) * 8u + (b & 7u)];
+    if (tile == 0xffffffffu) return;
+    const unsigned sub = (b >> 3) & 7u;
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const int lx = (int)((tile & 0xffffu) * FAST_TILE_W + (sub & 3u) * 8u + (lane & 7u));
+    const int ly = (int)((tile >> 16) * FAST_TILE_H + (sub >> 2) * 8u + (lane >> 3));
+    int px = lx, py;
+    if (P.stripe_count > 1) {
+        const int s = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (s * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    const bool in_image = !(px >= P.col_lim || py >= P.row_lim || py >= P.row_end);
+
+    Ray ray = {};
+    float t_min = 0.0f, t_max = 0.0f;
+    bool hit = false;
+    if (in_image) {
+        ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+        hit = intersect_ray_aabb(P, ray, t_min, t_max);
+    }
+    const int any_hit = __syncthreads_or(hit ? 1 : 0);
+    if (LUT && any_hit) {
+        const int n = P.max_val - P.min_val + 1;
+        for (int e = (int)threadIdx.x; e < n; e += 256) {
+            const float s = (float)(P.min_val + e);
+            const float v = div_cert(s - P.fmin, P.fden, P.rden);
+            const float a = v * P.alpha_scale;
+            lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
+        }
+    }
+    if (threadIdx.x < 64) { rs.rgb[0][threadIdx.x] = 0.0f; rs.a[0][threadIdx.x] = 0.0f; rs.i[0][threadIdx.x] = 0; }
+    if (threadIdx.x == 0) rs.seq = 0u;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
+    const float EPSILON = 0.000001f;
+    const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
+    float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
+    const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    const int nb = k_safe / RELAY_BATCH;                 // batches of THIS ray
+    int nbmax = nb;                                      // batches of the tile (same in all 4 wavefronts)
+    for (int o = 32; o > 0; o >>= 1) nbmax = max(nbmax, __shfl_xor(nbmax, o));
+
+    // voxel-unit copies for POW2 (see the fast kernel)
+    const float Sx = P.fdim[0], Sy = P.fdim[1], Sz = P.fdim[2];
+    float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
+    const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
+    const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+    const int lut_bias = -8 * P.min_val;
+
+    int adv = 0;                                         // batches the positions have been advanced through
+    auto step_position = [&]() {
+        if (POW2) { Qx += dSx; Qy += dSy; Qz += dSz; }
+        else { qx += dsx; qy += dsy; qz += dsz; }
+    };
+    auto advance_to = [&](int n) {                       // exact: the shader's additions, batch by batch
+        for (; adv < n; adv++)
+            if (adv < nb) {
+#pragma unroll
+                for (int u = 0; u < RELAY_BATCH; u++) step_position();
+            }
+    };
+    // gathers of batch n (if this ray still needs them); returns whether v[] is valid
+    auto issue = [&](int n, uint32_t (&v)[RELAY_BATCH], float da_seen) -> bool {
+        advance_to(n);
+        const bool need = n < nb && da_seen < 0.95f;
+        if (need) {
+            uint32_t off[RELAY_BATCH];
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) {
+                int vi, vj, vk;
+                if (POW2) {
+                    vi = (int)(Qx + Hx); vj = (int)(Qy + Hy); vk = (int)(Sz - (Qz + Hz));
+                } else {
+                    const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+                    const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+                    float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+                    uz = 1.0f - uz;
+                    vi = (int)(ux * P.fdim[0]); vj = (int)(uy * P.fdim[1]); vk = (int)(uz * P.fdim[2]);
+                }
+                off[u] = VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk);
+                step_position();
+            }
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) v[u] = VoxelFetch<VoxelT, false>::load(vol, rsrc, off[u]);
+        } else if (n < nb) {
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) step_position();   // a terminated ray: positions are dead, keep `adv` honest
+        }
+        adv = n + 1;
+        return need;
+    };
+    auto classify = [&](uint32_t texel, float &c, float &a) {
+        if (LUT) {
+            int t = (int)texel;
+            if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);
+            const float2 ca = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lut) + (uint32_t)((t << 3) + lut_bias));
+            c = ca.x; a = ca.y;
+        } else {
+            float s = (float)texel;
+            s = fminf(fmaxf(s, P.fmin), P.fmax);
+            s = div_cert(s - P.fmin, P.fden, P.rden);
+            a = s * P.alpha_scale;
+            c = s * a;
+        }
+    };
+    float da_seen = 0.0f;
+    // take over the recurrence for batch n, composite, hand it on
+    auto relay = [&](int n, const uint32_t (&v)[RELAY_BATCH], bool valid) {
+        float c[RELAY_BATCH], a[RELAY_BATCH];
+        if (valid) {
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) classify(v[u], c[u], a[u]);
+        }
+        while (__hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)n) __builtin_amdgcn_s_sleep(1);
+        const int slot = n & 1;
+        float drgb = rs.rgb[slot][lane], da = rs.a[slot][lane];
+        int i = rs.i[slot][lane];
+        if (valid) {
+            const float drgb0 = drgb, da0 = da;
+            float da_last = 0.0f;
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) {
+                if (u == RELAY_BATCH - 1) da_last = da;
+                const float om = 1.0f - da;
+                drgb += c[u] * om;
+                da += a[u] * om;
+            }
+            if (da_last < 0.95f) {
+                i += RELAY_BATCH;
+            } else {                                     // the batch in which the ray terminates: literal per-sample tests
+                drgb = drgb0; da = da0;
+#pragma unroll
+                for (int u = 0; u < RELAY_BATCH; u++) {
+                    if (da >= 0.95f) break;
+                    const float om = 1.0f - da;
+                    drgb += c[u] * om;
+                    da += a[u] * om;
+                    i++;
+                }
+            }
+        }
+        da_seen = da;
+        rs.rgb[slot ^ 1][lane] = drgb; rs.a[slot ^ 1][lane] = da; rs.i[slot ^ 1][lane] = i;
+        if (lane == 0) __hip_atomic_store(&rs.seq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    {
+        uint32_t va[RELAY_BATCH], vb[RELAY_BATCH];
+        bool ok_a = false, ok_b = false;
+        int n = (int)w;
+        if (n < nbmax) ok_a = issue(n, va, da_seen);
+        while (n < nbmax) {
+            if (n + RELAY_WAVES < nbmax) ok_b = issue(n + RELAY_WAVES, vb, da_seen);
+            relay(n, va, ok_a);
+            n += RELAY_WAVES;
+            if (n >= nbmax) break;
+            if (n + RELAY_WAVES < nbmax) ok_a = issue(n + RELAY_WAVES, va, da_seen);
+            relay(n, vb, ok_b);
+            n += RELAY_WAVES;
+        }
+    }
+    // the wavefront whose turn would be next finishes the rays: checked tail + store
+    if ((unsigned)(nbmax & (RELAY_WAVES - 1)) != w) return;
+    while (__hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)nbmax) __builtin_amdgcn_s_sleep(1);
+    float drgb = rs.rgb[nbmax & 1][lane], da = rs.a[nbmax & 1][lane];
+    int i = rs.i[nbmax & 1][lane];
+    advance_to(nbmax);
+    if (POW2) { qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz; }
+    if (hit) {
+        const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
+        for (; i < P.max_steps; i++) {
+            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            if (ux > 1.0f || uy > 1.0f || uz > 1.0f || ux < 0.0f || uy < 0.0f || uz < 0.0f || da >= 0.95f) break;
+            const int vi = min((int)(ux * P.fdim[0]), nxm1);
+            const int vj = min((int)(uy * P.fdim[1]), nym1);
+            const int vk = min((int)(uz * P.fdim[2]), nzm1);
+            float c, a;
+            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, a);
+            const float om = 1.0f - da;
+            drgb += c * om;
+            da += a * om;
+            qx += dsx; qy += dsy; qz += dsz;
+        }
+    }
+    if (!in_image) return;
+    const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+    fb[pix] = make_float4(drgb, drgb, drgb, da);
+    if (spp) spp[pix] = hit ? (uint32_t)i : 0u;
+}
+
 // ------------------------------------------------------------------ helper kernels
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -942,6 +1179,40 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
     return hipGetLastError();
 }
 
+// the relay kernel serves sparse launches of the headline shape (grey composite, default
+// view, 32-bit offsets, no skipping)
+static bool relay_selected(const FrameParams &P, const LaunchConfig &L)
+{
+    return L.sparse_shard && L.tile_table && !L.mip && P.tf_len <= 1 && !L.big_offsets && P.view_top != 1 &&
+           P.view_bottom != 1 && !(P.skip_empty != 0 && L.skip_grid != nullptr);
+}
+
+template <typename VoxelT, int LAYOUT>
+static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb, uint32_t *spp,
+                                 hipStream_t st)
+{
+    const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
+    const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+    const dim3 grid(L.tile_table_blocks * 8u), block(256);
+#define VR_RELAY(TC, LT, P2, NC)                                                                                  \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC>), grid, block, 0, st, P,         \
+                           (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table);                    \
+        return hipGetLastError();                                                                                 \
+    } while (0)
+    if (L.divmode_tc == DIV_CERT) {
+        if (lut) { if (noclamp) VR_RELAY(DIV_CERT, true, false, true); else VR_RELAY(DIV_CERT, true, false, false); }
+        VR_RELAY(DIV_CERT, false, false, false);
+    }
+    if (pow2) {
+        if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, true, true); else VR_RELAY(DIV_UNIT, true, true, false); }
+        VR_RELAY(DIV_UNIT, false, true, false);
+    }
+    if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, false, true); else VR_RELAY(DIV_UNIT, true, false, false); }
+    VR_RELAY(DIV_UNIT, false, false, false);
+#undef VR_RELAY
+}
+
 template <typename VoxelT, int LAYOUT, int VIEW, bool BIG, int MODE>
 static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                                  float4 *fb, uint32_t *spp, int rows, hipStream_t st)
@@ -949,12 +1220,14 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     // the no-clamp specialisation is kept for the headline mode only (compile time)
     const bool lut = L.use_lut != 0, noclamp = MODE == 0 && lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+    // sparse shards of the headline shape: four wavefronts relay one 8x8 tile
+    if (MODE == 0 && VIEW == 0 && !BIG && relay_selected(P, L))
+        return dispatch_relay<VoxelT, LAYOUT>(P, L, vol, fb, spp, st);
     // the skipping-free build exists for the headline shape only (MODE 0, default view)
     constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
 #define VR_LAUNCH(TC, LT, P2, NC)                                                                                         \
-    (noskip ? (L.sparse_shard ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, HEADLINE ? 16 : 8>(P, L, vol, tf, fb, spp, rows, st)  \
-                              : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8>(P, L, vol, tf, fb, spp, rows, st))                 \
+    (noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8>(P, L, vol, tf, fb, spp, rows, st) \
             : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true, 8>(P, L, vol, tf, fb, spp, rows, st))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
@@ -1030,7 +1303,7 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
     const bool count = spp != nullptr;
     const bool fast = fast_path_eligible(P, L);
-    if (kernel_name) *kernel_name = fast ? "raymarch_fast_kernel" : "raymarch_generic_kernel";
+    if (kernel_name) *kernel_name = !fast ? "raymarch_generic_kernel" : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel");
 #define VR_GO(T, LAY)                                                                                        \
     do {                                                                                                      \
         if (fast) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);                                 \
