@@ -12,8 +12,8 @@ print(f"# rocprofv3 summary, tag={tag}")
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name[-70:]
+    name = name.split("(")[0].replace("void ", "").replace("vr::", "").replace("unsigned short", "u16").replace("unsigned char", "u8")
+    return name[:70]
 
 
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
