@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--partition", choices=("stripes", "contiguous"), default="stripes")
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay)")
+    ap.add_argument("--shard", type=int, nargs=2, default=None, metavar=("WORLD", "RANK"),
+                    help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     ap.add_argument("--extras", action="store_true", help="also time the secondary regimes (shallow / trilinear)")
@@ -111,13 +114,18 @@ def main():
     if args.tf:   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59), black->white ramp
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
     r.setSkipEmpty(args.skip_empty)
+    r.setKernelVariant(args.kernel_variant)
     r.setAlpha(args.alpha)
     r.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
     if args.pose == "offaxis":
         r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)   # zenith 60 deg, azimuth 45 deg
 
     plan = sharding.plan_rows(H, world, rank, args.partition, args.stripe_rows)
+    if args.shard and world == 1:
+        plan = sharding.plan_rows(H, args.shard[0], args.shard[1], args.partition, args.stripe_rows)
     sharding.apply_plan(r, plan)
+    if args.shard and world == 1:
+        plan = sharding.RowPlan(H, 1, 0, "contiguous", args.stripe_rows, plan.local_rows)   # gather-free bookkeeping
     # a dedicated (non-null) torch stream: the kernel, the HIP events and RCCL all use it
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)

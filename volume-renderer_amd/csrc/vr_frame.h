@@ -54,7 +54,7 @@ struct LaunchConfig {
     uint32_t vol_bytes32;          // volume allocation size for the buffer descriptor (!big)
     const uint16_t *skip_grid;     // device: dilated per-cell max (nullptr = no skipping)
     uint32_t skip_grid_bytes;
-    int sparse_shard;              // the launch cannot fill the wave slots once: 4-wavefront relay kernel
+    int sparse_shard;              // use the 4-wavefront relay kernel when the shape allows
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;
 };

@@ -759,10 +759,10 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
 }
 
 // ------------------------------------------------------------------ relay kernel
-// Strong-scaling variant for launches that do not fill the chip's 8192 wave slots (one GPU's
-// shard of a 2..8-GPU frame: at N = 8 it is ~1300 ray tiles).  There a ray is a serial chain
-// of ~1000 dependent samples issued by ONE wavefront at ~300 cycles per sample, so a shard
-// costs >= 0.16 ms however idle the chip is.  Here FOUR wavefronts march one 8x8-pixel tile
+// A ray is a serial chain of ~1000 dependent samples; issued by ONE wavefront it advances at
+// ~300 cycles per sample, so a launch that cannot fill the chip's 8192 wave slots (one GPU's
+// shard of a multi-GPU frame) costs >= 0.16 ms however idle the chip is, and even the full
+// frame is only ~1.3 rounds of such chains.  Here FOUR wavefronts march one 8x8-pixel tile
 // as a relay: wavefront w owns batches w, w+4, w+8, ...; for its batch it generates the
 // addresses, gathers and classifies on its own, and only the front-to-back compositing
 // recurrence is handed from wavefront to wavefront through LDS (state = dest colour, dest
@@ -771,17 +771,28 @@ __global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
 // the shader's order; only WHICH wavefront executes them changes.
 // Same preconditions as the fast kernel's headline shape (NEAREST, grey-ramp composite,
 // iterative accumulation, default view, 32-bit offsets, alpha_scale in [0,1]).
-constexpr int RELAY_WAVES = 4, RELAY_BATCH = 8;   // batches of 16 measured the same, 32 spills
+#ifndef VR_RELAY_WAVES
+#define VR_RELAY_WAVES 4
+#endif
+// measured on cfg3: 2 or 8 wavefronts per tile, batches of 16, 4 tiles per workgroup are all slower
+constexpr int RELAY_WAVES = VR_RELAY_WAVES, RELAY_BATCH = 8;
+// two tiles share one workgroup (and one 32 KiB classification table): 4 workgroups = 8 tiles
+// = 32 wavefronts per CU, the wave-slot limit, instead of 4 tiles per CU
+constexpr int RELAY_TILES = 2, RELAY_THREADS = 64 * RELAY_WAVES * RELAY_TILES;
 
 struct RelayState {
     float rgb[2][64];
     float a[2][64];
     int i[2][64];
+    float pos[2][3][64];   // ray position at the start of batch n (slot n & 1)
     unsigned seq;          // number of batches composited so far
+    unsigned pseq;         // number of batches whose positions have been generated
+    unsigned stop;         // set when no ray of the tile needs another batch
+    unsigned final_n;      // the state slot holding the result is final_n & 1
 };
 
 template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP>
-__global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P,
+__global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const FrameParams P,
                                                              const VoxelT *__restrict__ vol,
                                                              const uint32_t vol_bytes,
                                                              float4 *__restrict__ fb,
@@ -789,14 +800,16 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
                                                              const uint32_t *__restrict__ tile_table)
 {
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];
-    __shared__ RelayState rs;
-    // block b -> (32x16 tile of the longest-first table, 8x8 sub-tile); the 8 sub-tiles of a
-    // tile are consecutive blocks of ONE XCD (b & 7 is the XCD)
+    __shared__ RelayState rs_all[RELAY_TILES];
+    // block b -> (32x16 tile of the longest-first table, pair of 8x8 sub-tiles); the 4 pairs of
+    // a tile are consecutive blocks of ONE XCD (b & 7 is the XCD)
     const unsigned b = blockIdx.x;
-    const uint32_t tile = tile_table[(b >> 6) * 8u + (b & 7u)];
+    const uint32_t tile = tile_table[(b >> 5) * 8u + (b & 7u)];
     if (tile == 0xffffffffu) return;
-    const unsigned sub = (b >> 3) & 7u;
-    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const unsigned tl = threadIdx.x / (64u * RELAY_WAVES);              // tile of this wavefront within the workgroup
+    RelayState &rs = rs_all[tl];
+    const unsigned sub = ((b >> 3) & 3u) * RELAY_TILES + tl;
+    const unsigned lane = threadIdx.x & 63u, w = (threadIdx.x >> 6) % RELAY_WAVES;
     const int lx = (int)((tile & 0xffffu) * FAST_TILE_W + (sub & 3u) * 8u + (lane & 7u));
     const int ly = (int)((tile >> 16) * FAST_TILE_H + (sub >> 2) * 8u + (lane >> 3));
     int px = lx, py;
@@ -818,15 +831,15 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
     const int any_hit = __syncthreads_or(hit ? 1 : 0);
     if (LUT && any_hit) {
         const int n = P.max_val - P.min_val + 1;
-        for (int e = (int)threadIdx.x; e < n; e += 256) {
+        for (int e = (int)threadIdx.x; e < n; e += RELAY_THREADS) {
             const float s = (float)(P.min_val + e);
             const float v = div_cert(s - P.fmin, P.fden, P.rden);
             const float a = v * P.alpha_scale;
             lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
         }
     }
-    if (threadIdx.x < 64) { rs.rgb[0][threadIdx.x] = 0.0f; rs.a[0][threadIdx.x] = 0.0f; rs.i[0][threadIdx.x] = 0; }
-    if (threadIdx.x == 0) rs.seq = 0u;
+    if (w == 0) { rs.rgb[0][lane] = 0.0f; rs.a[0][lane] = 0.0f; rs.i[0][lane] = 0; }
+    if (w == 0 && lane == 0) { rs.seq = 0u; rs.pseq = 0u; rs.stop = 0u; rs.final_n = 0u; }
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
@@ -839,53 +852,65 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
     int nbmax = nb;                                      // batches of the tile (same in all 4 wavefronts)
     for (int o = 32; o > 0; o >>= 1) nbmax = max(nbmax, __shfl_xor(nbmax, o));
 
-    // voxel-unit copies for POW2 (see the fast kernel)
+    // marching units: voxels for POW2 (see the fast kernel), box units otherwise.  Only the
+    // step is kept in registers; the position itself lives in LDS between wavefronts.
     const float Sx = P.fdim[0], Sy = P.fdim[1], Sz = P.fdim[2];
-    float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
-    const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
+    const float mx = POW2 ? dsx * Sx : dsx, my = POW2 ? dsy * Sy : dsy, mz = POW2 ? dsz * Sz : dsz;
     const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
     const int lut_bias = -8 * P.min_val;
 
-    int adv = 0;                                         // batches the positions have been advanced through
-    auto step_position = [&]() {
-        if (POW2) { Qx += dSx; Qy += dSy; Qz += dSz; }
-        else { qx += dsx; qy += dsy; qz += dsz; }
+    // The ray positions travel the same way as the compositing state: the wavefront that
+    // generated the addresses of batch n publishes the position at the start of batch n+1
+    // (every addition is the shader's, performed once, in order).
+    if (w == 0) {
+        rs.pos[0][0][lane] = POW2 ? qx * Sx : qx; rs.pos[0][1][lane] = POW2 ? qy * Sy : qy; rs.pos[0][2][lane] = POW2 ? qz * Sz : qz;
+    }
+    __syncthreads();
+    // both wait loops give up when the tile has been stopped (early ray termination of every
+    // ray, or the last batch): returns false, nothing may be touched any more
+    auto wait_for = [&](const unsigned *word, int n) -> bool {
+        while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)n) {
+            if (__hip_atomic_load(&rs.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return __hip_atomic_load(&rs.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
     };
-    auto advance_to = [&](int n) {                       // exact: the shader's additions, batch by batch
-        for (; adv < n; adv++)
-            if (adv < nb) {
-#pragma unroll
-                for (int u = 0; u < RELAY_BATCH; u++) step_position();
-            }
+    bool stopped = false;
+    auto take_position = [&](int n, float &x, float &y, float &z) -> bool {
+        if (!wait_for(&rs.pseq, n)) return false;
+        x = rs.pos[n & 1][0][lane]; y = rs.pos[n & 1][1][lane]; z = rs.pos[n & 1][2][lane];
+        return true;
     };
     // gathers of batch n (if this ray still needs them); returns whether v[] is valid
     auto issue = [&](int n, uint32_t (&v)[RELAY_BATCH], float da_seen) -> bool {
-        advance_to(n);
+        float x = 0.0f, y = 0.0f, z = 0.0f;
+        if (stopped || !take_position(n, x, y, z)) { stopped = true; return false; }
         const bool need = n < nb && da_seen < 0.95f;
-        if (need) {
-            uint32_t off[RELAY_BATCH];
+        uint32_t off[RELAY_BATCH];
+        if (n < nb) {
 #pragma unroll
             for (int u = 0; u < RELAY_BATCH; u++) {
                 int vi, vj, vk;
                 if (POW2) {
-                    vi = (int)(Qx + Hx); vj = (int)(Qy + Hy); vk = (int)(Sz - (Qz + Hz));
+                    vi = (int)(x + Hx); vj = (int)(y + Hy); vk = (int)(Sz - (z + Hz));
                 } else {
-                    const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-                    const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-                    float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+                    const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+                    const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+                    float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
                     uz = 1.0f - uz;
                     vi = (int)(ux * P.fdim[0]); vj = (int)(uy * P.fdim[1]); vk = (int)(uz * P.fdim[2]);
                 }
                 off[u] = VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk);
-                step_position();
+                x += mx; y += my; z += mz;
             }
+        }
+        // position at the start of batch n + 1
+        rs.pos[(n + 1) & 1][0][lane] = x; rs.pos[(n + 1) & 1][1][lane] = y; rs.pos[(n + 1) & 1][2][lane] = z;
+        if (lane == 0) __hip_atomic_store(&rs.pseq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (need) {
 #pragma unroll
             for (int u = 0; u < RELAY_BATCH; u++) v[u] = VoxelFetch<VoxelT, false>::load(vol, rsrc, off[u]);
-        } else if (n < nb) {
-#pragma unroll
-            for (int u = 0; u < RELAY_BATCH; u++) step_position();   // a terminated ray: positions are dead, keep `adv` honest
         }
-        adv = n + 1;
         return need;
     };
     auto classify = [&](uint32_t texel, float &c, float &a) {
@@ -910,7 +935,7 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
 #pragma unroll
             for (int u = 0; u < RELAY_BATCH; u++) classify(v[u], c[u], a[u]);
         }
-        while (__hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)n) __builtin_amdgcn_s_sleep(1);
+        if (stopped || !wait_for(&rs.seq, n)) { stopped = true; return; }
         const int slot = n & 1;
         float drgb = rs.rgb[slot][lane], da = rs.a[slot][lane];
         int i = rs.i[slot][lane];
@@ -940,6 +965,16 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
         }
         da_seen = da;
         rs.rgb[slot ^ 1][lane] = drgb; rs.a[slot ^ 1][lane] = da; rs.i[slot ^ 1][lane] = i;
+        // does any ray of the tile need another batch?  (terminated rays and rays whose prefix
+        // ends here do not)
+        const bool more = hit && da < 0.95f && n + 1 < nb;
+        if (!__any(more ? 1 : 0)) {
+            if (lane == 0) {
+                rs.final_n = (unsigned)(n + 1);
+                __hip_atomic_store(&rs.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            stopped = true;
+        }
         if (lane == 0) __hip_atomic_store(&rs.seq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
@@ -948,23 +983,31 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
         bool ok_a = false, ok_b = false;
         int n = (int)w;
         if (n < nbmax) ok_a = issue(n, va, da_seen);
-        while (n < nbmax) {
+        while (n < nbmax && !stopped) {
             if (n + RELAY_WAVES < nbmax) ok_b = issue(n + RELAY_WAVES, vb, da_seen);
             relay(n, va, ok_a);
             n += RELAY_WAVES;
-            if (n >= nbmax) break;
+            if (n >= nbmax || stopped) break;
             if (n + RELAY_WAVES < nbmax) ok_a = issue(n + RELAY_WAVES, va, da_seen);
             relay(n, vb, ok_b);
             n += RELAY_WAVES;
         }
     }
-    // the wavefront whose turn would be next finishes the rays: checked tail + store
-    if ((unsigned)(nbmax & (RELAY_WAVES - 1)) != w) return;
-    while (__hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)nbmax) __builtin_amdgcn_s_sleep(1);
-    float drgb = rs.rgb[nbmax & 1][lane], da = rs.a[nbmax & 1][lane];
-    int i = rs.i[nbmax & 1][lane];
-    advance_to(nbmax);
-    if (POW2) { qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz; }
+    // every wavefront of the workgroup leaves its relay loop exactly once; afterwards the
+    // state / position words are quiescent and wavefront 0 of each tile finishes the rays
+    __syncthreads();
+    if (w != 0) return;
+    const unsigned fin = rs.final_n;                     // == nbmax unless the tile stopped early
+    float drgb = rs.rgb[fin & 1][lane], da = rs.a[fin & 1][lane];
+    int i = rs.i[fin & 1][lane];
+    {
+        // a ray that still needs its tail finished its prefix at batch nb <= fin <= pseq, and its
+        // position has not changed since; pos(pseq) is the latest published
+        const unsigned pn = rs.pseq;
+        qx = rs.pos[pn & 1][0][lane]; qy = rs.pos[pn & 1][1][lane]; qz = rs.pos[pn & 1][2][lane];
+    }
+    if (POW2) { qx = qx / Sx; qy = qy / Sy; qz = qz / Sz; }   // exact: S is a power of two
+    const float tsx = POW2 ? mx / Sx : mx, tsy = POW2 ? my / Sy : my, tsz = POW2 ? mz / Sz : mz;
     if (hit) {
         const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
         for (; i < P.max_steps; i++) {
@@ -981,7 +1024,7 @@ __global__ __launch_bounds__(256) void raymarch_relay_kernel(const FrameParams P
             const float om = 1.0f - da;
             drgb += c * om;
             da += a * om;
-            qx += dsx; qy += dsy; qz += dsz;
+            qx += tsx; qy += tsy; qz += tsz;
         }
     }
     if (!in_image) return;
@@ -1179,8 +1222,9 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
     return hipGetLastError();
 }
 
-// the relay kernel serves sparse launches of the headline shape (grey composite, default
-// view, 32-bit offsets, no skipping)
+// the relay kernel serves the headline shape (grey composite, default view, 32-bit offsets,
+// no skipping): it beats the lockstep fast kernel at every launch size measured (cfg3 frame
+// 0.59 vs 0.63 ms, 1/8 shard 0.095 vs 0.18 ms); L.sparse_shard is its on/off switch
 static bool relay_selected(const FrameParams &P, const LaunchConfig &L)
 {
     return L.sparse_shard && L.tile_table && !L.mip && P.tf_len <= 1 && !L.big_offsets && P.view_top != 1 &&
@@ -1193,7 +1237,7 @@ static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, co
 {
     const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-    const dim3 grid(L.tile_table_blocks * 8u), block(256);
+    const dim3 grid(L.tile_table_blocks * (8u / RELAY_TILES)), block(RELAY_THREADS);
 #define VR_RELAY(TC, LT, P2, NC)                                                                                  \
     do {                                                                                                          \
         hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC>), grid, block, 0, st, P,         \
