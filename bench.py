@@ -341,6 +341,28 @@ def cpu_baseline(args, r, frame, gpu_msamples):
     out, samples, secs = run(rows, 1)
     diff = float(np.max(np.abs(out[rows] - gpu[rows])))
     bitexact = bool(np.array_equal(out[rows].view(np.uint32), gpu[rows].view(np.uint32)))
+
+    # the OpenMP row-parallel variant of the same oracle on every host core: a
+    # contiguous block of rows about the image centre sized for ~5 s
+    cores = os.cpu_count() or 1
+    all_cores = None
+    if cores > 1:
+        per_row = max(ps / len(probe_rows), 1.0)
+        nrows = int(min(H, max(cores, rate * cores * 5.0 / per_row)))
+        y0 = max(0, H // 2 - nrows // 2)
+        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1],
+                                filter=1 if args.filter == "trilinear" else 0, threads=cores, tf_rgba=tf)
+        p.row_begin, p.row_end = y0, min(H, y0 + nrows)
+        out2 = np.zeros((H, W, 4), dtype=np.float32)
+        t0 = time.perf_counter()
+        _, s2 = oracle.render(vol, p, out=out2)
+        t2 = time.perf_counter() - t0
+        blk = slice(p.row_begin, p.row_end)
+        all_cores = {
+            "value": round(s2 / t2 / 1e6, 2), "unit": "Msamples/s", "cores": cores,
+            "sample": f"rows {p.row_begin}..{p.row_end - 1} ({s2} samples, {t2:.1f} s), OpenMP over rows",
+            "parity_bit_exact_on_sample": bool(np.array_equal(out2[blk].view(np.uint32), gpu[blk].view(np.uint32))),
+        }
     return {
         "value": round(samples / secs / 1e6, 2),
         "unit": "Msamples/s",
@@ -351,6 +373,7 @@ def cpu_baseline(args, r, frame, gpu_msamples):
         "parity_max_abs_diff_on_sample": diff,
         "parity_bit_exact_on_sample": bitexact,
         "gpu_over_cpu": round(gpu_msamples / (samples / secs / 1e6), 1),
+        "all_cores": all_cores,
     }
 
 

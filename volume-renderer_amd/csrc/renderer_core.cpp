@@ -167,10 +167,15 @@ bool RendererCore::loadShader(std::string fn, bool reload)
 }
 
 // ---------------------------------------------------------------- volume
+// bricks per axis of the VR_LAYOUT_BRICKED storage (vr_frame.h: BRICK_X x BRICK_Y x BRICK_Z voxels)
+static inline uint32_t bricksX(int n) { return (uint32_t)((n + BRICK_X - 1) / BRICK_X); }
+static inline uint32_t bricksY(int n) { return (uint32_t)((n + BRICK_Y - 1) / BRICK_Y); }
+static inline uint32_t bricksZ(int n) { return (uint32_t)((n + BRICK_Z - 1) / BRICK_Z); }
+
 size_t RendererCore::storageVoxels(int nx, int ny, int nz, int lay) const
 {
     if (lay == 0) return (size_t)nx * (size_t)ny * (size_t)nz;
-    return (size_t)((nx + 3) / 4) * (size_t)((ny + 3) / 4) * (size_t)((nz + 3) / 4) * 64u;
+    return (size_t)bricksX(nx) * (size_t)bricksY(ny) * (size_t)bricksZ(nz) * 64u;
 }
 
 void RendererCore::freeVolume()
@@ -197,7 +202,7 @@ void RendererCore::setVolume(const void *host, int nx, int ny, int nz, int bytes
         throw std::invalid_argument("setVolume: bad dimensions or datasize_bytes");
     requireDevice("setVolume");
     const size_t lin_bytes = (size_t)nx * (size_t)ny * (size_t)nz * (size_t)bytes;
-    const uint32_t bnx = (uint32_t)((nx + 3) / 4), bny = (uint32_t)((ny + 3) / 4);
+    const uint32_t bnx = bricksX(nx), bny = bricksY(ny);
     if (layout == 0) {
         allocVolume(nx, ny, nz, bytes, 0);
         check(hipMemcpyAsync(d_vol_, host, lin_bytes, hipMemcpyHostToDevice, stream()), "hipMemcpy(volume)");
@@ -228,7 +233,7 @@ void RendererCore::generateSynthetic(int kind, int nx, int ny, int nz, int bytes
     requireDevice("generateSynthetic");
     allocVolume(nx, ny, nz, bytes, layout);
     check(launch_gen_volume(d_vol_, bytes, kind, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, param, layout,
-                            (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), stream()),
+                            bricksX(nx), bricksY(ny), stream()),
           "gen_volume_kernel");
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
     tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
@@ -251,8 +256,8 @@ void RendererCore::readVolume(void *host, size_t bytes)
     void *staging = nullptr;
     check(hipMalloc(&staging, lin_bytes), "hipMalloc(staging)");
     hipError_t e = launch_relayout(d_vol_, staging, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1],
-                                   (uint32_t)tex3D_dim[2], (uint32_t)((tex3D_dim[0] + 3) / 4),
-                                   (uint32_t)((tex3D_dim[1] + 3) / 4), 1, stream());
+                                   (uint32_t)tex3D_dim[2], bricksX(tex3D_dim[0]),
+                                   bricksY(tex3D_dim[1]), 1, stream());
     if (e == hipSuccess) e = hipMemcpyAsync(host, staging, lin_bytes, hipMemcpyDeviceToHost, stream());
     if (e == hipSuccess) e = hipStreamSynchronize(stream());
     (void)hipFree(staging);
@@ -270,7 +275,7 @@ void RendererCore::setLayout(int lay)
     d_vol_ = nullptr;
     try { allocVolume(nx, ny, nz, datasize_bytes, lay); } catch (...) { d_vol_ = old; throw; }
     hipError_t e = launch_relayout(old, d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz,
-                                   (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), lay == 0 ? 1 : 0, stream());
+                                   bricksX(nx), bricksY(ny), lay == 0 ? 1 : 0, stream());
     if (e == hipSuccess) e = hipStreamSynchronize(stream());
     (void)hipFree(old);
     check(e, "relayout");
@@ -283,7 +288,7 @@ void RendererCore::scanDatasetRange()
     const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
     check(hipMemcpyAsync(d_scratch_, init, sizeof(init), hipMemcpyHostToDevice, stream()), "hipMemcpy(scratch)");
     check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
-                       vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 0, 1.0f,
+                       vol_layout_, bricksX(tex3D_dim[0]), bricksY(tex3D_dim[1]), 0, 1.0f,
                        d_scratch_, d_scratch_ + 4, stream()),
           "stats_kernel");
     unsigned mm[4];
@@ -309,7 +314,7 @@ void RendererCore::computeHistogram(float out[256])
     if (!d_vol_) throw std::runtime_error("histogram: no dataset loaded");
     check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned) * 264, stream()), "hipMemset(scratch)");
     check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
-                       vol_layout_, (uint32_t)((tex3D_dim[0] + 3) / 4), (uint32_t)((tex3D_dim[1] + 3) / 4), 1,
+                       vol_layout_, bricksX(tex3D_dim[0]), bricksY(tex3D_dim[1]), 1,
                        (float)max_dataset_val, d_scratch_, d_scratch_ + 4, stream()),
           "stats_kernel");
     unsigned counts[256];
@@ -495,7 +500,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
     P.nx = nx; P.ny = ny; P.nz = nz;
     P.fdim[0] = (float)nx; P.fdim[1] = (float)ny; P.fdim[2] = (float)nz;
-    P.bnx = (nx + 3) / 4; P.bny = (ny + 3) / 4; P.bnz = (nz + 3) / 4;
+    P.bnx = (int)bricksX(nx); P.bny = (int)bricksY(ny); P.bnz = (int)bricksZ(nz);
     // ---- main(): VolumeRenderer.cs:65-83
     int max_dim = std::max(nx, ny);
     max_dim = std::max(max_dim, nz);
@@ -536,7 +541,9 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.generic = force_generic == 1 ? 1 : 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
-        const uint64_t bsy = 64ull * (uint64_t)P.bnx - 16ull, bsz = 64ull * (uint64_t)P.bnx * (uint64_t)P.bny - 64ull;
+        // VoxelAddr: the strides carry minus the part of the in-brick term the split axis repeats
+        const uint64_t bsy = 64ull * (uint64_t)P.bnx - (BRICK_LY ? (uint64_t)(BRICK_X * BRICK_Y) : 0ull);
+        const uint64_t bsz = 64ull * (uint64_t)P.bnx * (uint64_t)P.bny - (BRICK_LZ ? 64ull : 0ull);
         P.bstride_y = (uint32_t)bsy;
         P.bstride_z = (uint32_t)bsz;
         const uint64_t storage = storageVoxels(nx, ny, nz, vol_layout_);
@@ -625,7 +632,7 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_skip_grid_), cells * sizeof(uint16_t));
         if (e == hipSuccess)
             e = launch_build_skip_grid(d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, vol_layout_,
-                                       (uint32_t)((nx + 3) / 4), (uint32_t)((ny + 3) / 4), tmp, d_skip_grid_, stream());
+                                       bricksX(nx), bricksY(ny), tmp, d_skip_grid_, stream());
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         (void)hipFree(tmp);
         if (e != hipSuccess && d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; }

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace vr {
@@ -64,45 +66,56 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
     unsigned active_tiles = 0;
     const unsigned tiles_x = (unsigned)((P.img_w + (int)kFastTileW - 1) / (int)kFastTileW);
     const unsigned tiles_y = (unsigned)((rows + (int)kFastTileH - 1) / (int)kFastTileH);
-    const unsigned cpr = (tiles_x + kFastChunk - 1) / kFastChunk;
-    struct Chunk { double work; unsigned cx, ty; };
+    // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
+    // single tiles win -- balance across the XCDs matters more than sharing brick rows in one
+    // L2 (0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4).  VR_EXP_CHUNK=WxH overrides (experiments).
+    unsigned CW = kFastChunkW, CH = kFastChunkH;
+    if (const char *e = std::getenv("VR_EXP_CHUNK")) { unsigned a = 0, b = 0; if (std::sscanf(e, "%ux%u", &a, &b) == 2 && a && b) { CW = a; CH = b; } }
+    if (P.stripe_count > 1) CH = 1;          // cyclic stripes: vertically adjacent local tiles are not neighbours
+    const unsigned cpr = (tiles_x + CW - 1) / CW, cpc = (tiles_y + CH - 1) / CH, per_chunk = CW * CH;
+    struct Chunk { double work; unsigned cx, cy; };
     std::vector<Chunk> chunks;
-    chunks.reserve((size_t)cpr * tiles_y);
+    chunks.reserve((size_t)cpr * cpc);
+    std::vector<double> tile_work((size_t)tiles_x * tiles_y, 0.0);
     for (unsigned ty = 0; ty < tiles_y; ty++) {
         // probe rows: top, middle, bottom of the tile (global rows of this shard)
         const int ly0 = (int)(ty * kFastTileH);
         const int pr[3] = {globalRow(P, ly0), globalRow(P, ly0 + (int)kFastTileH / 2), globalRow(P, ly0 + (int)kFastTileH - 1)};
-        for (unsigned cx = 0; cx < cpr; cx++) {
-            double work = 0.0;
-            for (unsigned t = 0; t < kFastChunk; t++) {
-                const unsigned tx = cx * kFastChunk + t;
-                if (tx >= tiles_x) break;
-                const double x0 = tx * (double)kFastTileW;
-                double wmax = 0.0;
-                for (int r = 0; r < 3; r++)
-                    for (int k = 0; k < 3; k++) {
-                        const double px = std::min(x0 + k * ((double)kFastTileW - 1.0) / 2.0, (double)P.img_w - 1.0) + 0.5;
-                        const double py = std::min((double)pr[r], (double)P.img_h - 1.0) + 0.5;
-                        wmax = std::max(wmax, raySamples(P, px, py));
-                    }
-                work += wmax;
-                if (wmax > 0.0) active_tiles++;
-            }
-            chunks.push_back({work, cx, ty});
+        for (unsigned tx = 0; tx < tiles_x; tx++) {
+            const double x0 = tx * (double)kFastTileW;
+            double wmax = 0.0;
+            for (int r = 0; r < 3; r++)
+                for (int k = 0; k < 3; k++) {
+                    const double px = std::min(x0 + k * ((double)kFastTileW - 1.0) / 2.0, (double)P.img_w - 1.0) + 0.5;
+                    const double py = std::min((double)pr[r], (double)P.img_h - 1.0) + 0.5;
+                    wmax = std::max(wmax, raySamples(P, px, py));
+                }
+            tile_work[(size_t)ty * tiles_x + tx] = wmax;
+            if (wmax > 0.0) active_tiles++;
         }
     }
+    for (unsigned cy = 0; cy < cpc; cy++)
+        for (unsigned cx = 0; cx < cpr; cx++) {
+            double work = 0.0;
+            for (unsigned v = 0; v < CH; v++)
+                for (unsigned u = 0; u < CW; u++) {
+                    const unsigned tx = cx * CW + u, ty = cy * CH + v;
+                    if (tx < tiles_x && ty < tiles_y) work += tile_work[(size_t)ty * tiles_x + tx];
+                }
+            chunks.push_back({work, cx, cy});
+        }
     std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.work > b.work; });
     // chunk of rank r -> XCD r % 8, its (r / 8)-th chunk; block b runs on XCD b % 8
     const size_t nchunks = chunks.size();
     const size_t per_xcd = (nchunks + 7) / 8;
-    table.assign(per_xcd * 8 * kFastChunk, kTilePadding);
+    table.assign(per_xcd * 8 * per_chunk, kTilePadding);
     for (size_t r = 0; r < nchunks; r++) {
         const size_t xcd = r % 8, pos = r / 8;
-        for (unsigned t = 0; t < kFastChunk; t++) {
-            const unsigned tx = chunks[r].cx * kFastChunk + t;
-            if (tx >= tiles_x) continue;
-            const size_t b = (pos * kFastChunk + t) * 8 + xcd;
-            table[b] = tx | (chunks[r].ty << 16);
+        for (unsigned t = 0; t < per_chunk; t++) {
+            const unsigned tx = chunks[r].cx * CW + t % CW, ty = chunks[r].cy * CH + t / CW;
+            if (tx >= tiles_x || ty >= tiles_y) continue;
+            const size_t b = (pos * per_chunk + t) * 8 + xcd;
+            table[b] = tx | (ty << 16);
         }
     }
     return active_tiles;

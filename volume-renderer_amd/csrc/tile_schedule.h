@@ -2,9 +2,9 @@
 //
 // Rays that cross the whole volume take ~4x longer than rays clipping a corner, and one
 // frame is only ~1.3 "rounds" of resident wavefronts, so dispatch order decides the tail:
-// blocks are issued longest-first (LPT), dealt round-robin to the 8 XCDs in chunks of
-// horizontally adjacent tiles (shared cache lines stay on one XCD's L2).  A scheduling
-// heuristic only: pixels are independent, the image does not depend on it.
+// blocks are issued longest-first (LPT) and dealt round-robin to the 8 XCDs (block b runs
+// on XCD b % 8).  A scheduling heuristic only: pixels are independent, the image does not
+// depend on it.
 #pragma once
 #include <stdint.h>
 
@@ -14,7 +14,8 @@
 
 namespace vr {
 
-constexpr unsigned kFastTileW = 32, kFastTileH = 16, kFastChunk = 4;
+constexpr unsigned kFastTileW = 32, kFastTileH = 16, kFastChunk = 4;   // kFastChunk: table-less fallback order
+constexpr unsigned kFastChunkW = 1, kFastChunkH = 1;                    // chunk of tiles dealt to one XCD
 constexpr uint32_t kTilePadding = 0xffffffffu;
 
 // table[b] = tile_x | tile_y << 16 for block b, kTilePadding for padding blocks.

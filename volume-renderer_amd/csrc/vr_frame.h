@@ -9,6 +9,18 @@ namespace vr {
 
 enum : int { DIV_UNIT = 0, DIV_CERT = 1, DIV_EXACT = 2 };
 
+// VR_LAYOUT_BRICKED: the volume is stored as bricks of 64 voxels (128 B of u16, one cache
+// line; 64 B of u8), BRICK_X x BRICK_Y x BRICK_Z voxels each, x fastest inside a brick,
+// bricks in x-y-z order.  The shape is a build constant shared by host and kernels.
+#ifndef VR_BRICK_LX
+#define VR_BRICK_LX 2
+#define VR_BRICK_LY 2
+#define VR_BRICK_LZ 2
+#endif
+constexpr int BRICK_LX = VR_BRICK_LX, BRICK_LY = VR_BRICK_LY, BRICK_LZ = VR_BRICK_LZ;
+constexpr int BRICK_X = 1 << BRICK_LX, BRICK_Y = 1 << BRICK_LY, BRICK_Z = 1 << BRICK_LZ;
+static_assert(BRICK_LX + BRICK_LY + BRICK_LZ == 6 && BRICK_LX >= 1, "bricks hold 64 voxels");
+
 struct FrameParams {
     float cam[21];                 // view_mat columns, eye, view_plane_dist
     int32_t img_w, img_h;          // imageSize(render_texture)
@@ -36,7 +48,7 @@ struct FrameParams {
     int32_t cnx, cny, cnz;         // cells (8x8x8 voxels) per axis
     // bricked layout (VR_LAYOUT_BRICKED): bricks of 4x4x4 voxels, x-fastest inside
     int32_t bnx, bny, bnz;         // bricks per axis
-    uint32_t bstride_y, bstride_z; // 64*bnx - 16 and 64*bnx*bny - 64 (see VoxelAddr)
+    uint32_t bstride_y, bstride_z; // brick-row / brick-slab strides minus the in-brick part (see VoxelAddr)
 };
 
 struct LaunchConfig {

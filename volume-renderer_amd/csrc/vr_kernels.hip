@@ -138,9 +138,10 @@ __device__ __forceinline__ float fetch_voxel(const FrameParams &P, const VoxelT 
                              (uint64_t)(uint32_t)P.nx * ((uint64_t)(uint32_t)j + (uint64_t)(uint32_t)P.ny * (uint64_t)(uint32_t)k);
         return (float)vol[idx];
     } else {
-        const uint32_t bi = (uint32_t)i >> 2, bj = (uint32_t)j >> 2, bk = (uint32_t)k >> 2;
+        const uint32_t bi = (uint32_t)i >> BRICK_LX, bj = (uint32_t)j >> BRICK_LY, bk = (uint32_t)k >> BRICK_LZ;
         const uint64_t brick = (uint64_t)bi + (uint64_t)(uint32_t)P.bnx * ((uint64_t)bj + (uint64_t)(uint32_t)P.bny * (uint64_t)bk);
-        const uint32_t in = ((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4);
+        const uint32_t in = ((uint32_t)i & (BRICK_X - 1u)) | (((uint32_t)j & (BRICK_Y - 1u)) << BRICK_LX) |
+                            (((uint32_t)k & (BRICK_Z - 1u)) << (BRICK_LX + BRICK_LY));
         return (float)vol[brick * 64u + in];
     }
 }
@@ -325,17 +326,21 @@ struct VoxelAddr {
             return (type)mad_u24(row, (uint32_t)P.nx, (uint32_t)i);
         } else {
             if (BIG) {
-                const uint64_t brick = (uint64_t)((uint32_t)i >> 2) + (uint64_t)(uint32_t)P.bnx * ((uint64_t)((uint32_t)j >> 2) + (uint64_t)(uint32_t)P.bny * (uint64_t)((uint32_t)k >> 2));
-                return (type)(brick * 64u + (((uint32_t)i & 3u) | (((uint32_t)j & 3u) << 2) | (((uint32_t)k & 3u) << 4)));
+                const uint64_t brick = (uint64_t)((uint32_t)i >> BRICK_LX) + (uint64_t)(uint32_t)P.bnx * ((uint64_t)((uint32_t)j >> BRICK_LY) + (uint64_t)(uint32_t)P.bny * (uint64_t)((uint32_t)k >> BRICK_LZ));
+                return (type)(brick * 64u + (((uint32_t)i & (BRICK_X - 1u)) | (((uint32_t)j & (BRICK_Y - 1u)) << BRICK_LX) |
+                                             (((uint32_t)k & (BRICK_Z - 1u)) << (BRICK_LX + BRICK_LY))));
             }
-            // (i&3) + (i>>2)*64 = i + (i>>2)*60, likewise j (x4) and k (x16):
-            //   offset = [i + 4j + 16k] + 60*(i>>2) + bstride_y*(j>>2) + bstride_z*(k>>2)
-            // = 2 shift-adds + 3 shifts + 3 chained 24-bit mads
-            uint32_t t = ((uint32_t)j << 2) + (uint32_t)i;
-            t = ((uint32_t)k << 4) + t;
-            t = mad_u24((uint32_t)i >> 2, 60u, t);
-            t = mad_u24((uint32_t)j >> 2, P.bstride_y, t);
-            return (type)mad_u24((uint32_t)k >> 2, P.bstride_z, t);
+            // (i & (BX-1)) + 64*(i>>LX) = i + (64-BX)*(i>>LX); likewise j (scaled by BX) and k
+            // (scaled by BX*BY):
+            //   offset = [i + BX*j + BX*BY*k] + (64-BX)*(i>>LX) + bstride_y*(j>>LY) + bstride_z*(k>>LZ)
+            // = 2 shift-adds + 3 shifts + 3 chained 24-bit mads; an axis the brick does not
+            // split (L == 0) is one mad with the full stride
+            uint32_t t = (uint32_t)i;
+            if (BRICK_LY) t = ((uint32_t)j << BRICK_LX) + t;
+            if (BRICK_LZ) t = ((uint32_t)k << (BRICK_LX + BRICK_LY)) + t;
+            t = mad_u24((uint32_t)i >> BRICK_LX, 64u - (uint32_t)BRICK_X, t);
+            t = mad_u24(BRICK_LY ? (uint32_t)j >> BRICK_LY : (uint32_t)j, P.bstride_y, t);
+            return (type)mad_u24(BRICK_LZ ? (uint32_t)k >> BRICK_LZ : (uint32_t)k, P.bstride_z, t);
         }
     }
 };
@@ -425,7 +430,13 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // of occupancy per CU, so the headline variant is also built without it).
 // BATCH: samples per gather batch (8: the skip grid's dilation covers exactly that).
 template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
-__global__ __launch_bounds__(512) void raymarch_fast_kernel(const FrameParams P,
+#ifndef VR_EXP_FAST_OCC          // experiment knobs: waves per SIMD asked of the compiler, batch length
+#define VR_EXP_FAST_OCC 1
+#endif
+#ifndef VR_EXP_FAST_BATCH
+#define VR_EXP_FAST_BATCH 8
+#endif
+__global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const float4 *__restrict__ tf,
                                                             const uint32_t vol_bytes,
@@ -1053,8 +1064,8 @@ __device__ __forceinline__ uint64_t storage_index(int layout, uint32_t i, uint32
                                                   uint32_t ny, uint32_t bnx, uint32_t bny)
 {
     if (layout == 0) return (uint64_t)i + (uint64_t)nx * ((uint64_t)j + (uint64_t)ny * (uint64_t)k);
-    const uint64_t brick = (uint64_t)(i >> 2) + (uint64_t)bnx * ((uint64_t)(j >> 2) + (uint64_t)bny * (uint64_t)(k >> 2));
-    return brick * 64u + ((i & 3u) | ((j & 3u) << 2) | ((k & 3u) << 4));
+    const uint64_t brick = (uint64_t)(i >> BRICK_LX) + (uint64_t)bnx * ((uint64_t)(j >> BRICK_LY) + (uint64_t)bny * (uint64_t)(k >> BRICK_LZ));
+    return brick * 64u + ((i & (BRICK_X - 1u)) | ((j & (BRICK_Y - 1u)) << BRICK_LX) | ((k & (BRICK_Z - 1u)) << (BRICK_LX + BRICK_LY)));
 }
 
 template <typename VoxelT>
@@ -1298,6 +1309,16 @@ static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, co
     return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 0>(P, L, vol, tf, fb, spp, rows, st);
 }
 
+#ifdef VR_EXP_HEADLINE_ONLY      // experiment builds only: just the cfg3 headline instance (fast compile)
+template <typename VoxelT, int LAYOUT>
+static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
+                                float4 *fb, uint32_t *spp, int rows, hipStream_t st)
+{
+    if constexpr (sizeof(VoxelT) == 2 && LAYOUT == 1)
+        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH>(P, L, vol, tf, fb, spp, rows, st);
+    return hipErrorInvalidValue;
+}
+#else
 template <typename VoxelT, int LAYOUT>
 static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                                 float4 *fb, uint32_t *spp, int rows, hipStream_t st)
@@ -1312,6 +1333,7 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
     if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, false>(P, L, vol, tf, fb, spp, rows, st);
     return dispatch_fast2<VoxelT, LAYOUT, 2, false>(P, L, vol, tf, fb, spp, rows, st);
 }
+#endif
 
 // The specialised kernel covers NEAREST + iterative accumulation with a non-degenerate
 // window whose divisions were certified and alpha_scale in [0,1]: grey-ramp composite,
