@@ -265,6 +265,18 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        if world == 1:
+            # the box's own achievable HBM read rate (streaming read of the resident volume),
+            # measured after the timed region ("confirm the peak on the box")
+            try:
+                stream_gbps = r.measureStreamRead(5)
+                vol_bytes = int(dims[0]) * int(dims[1]) * int(dims[2]) * b
+                result["roofline"]["measured_stream_read"] = round(stream_gbps, 1)
+                # reading the volume once + writing the frame at that rate: the floor of any layout
+                result["roofline"]["compulsory_floor_ms"] = round((vol_bytes + W * H * 16) / stream_gbps / 1e6, 4)
+            except Exception as exc:                      # measurement aid only
+                result["roofline"]["measured_stream_read"] = None
+                print(f"[bench] stream-read probe failed: {exc}", file=sys.stderr)
         if world > 1:
             result["multi_gpu_frame_bit_exact"] = gather_ok
             result["overlap"] = "all_gather of frame i on a second stream overlaps the kernel of frame i+1"

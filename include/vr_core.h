@@ -104,6 +104,10 @@ int vr_get_dims(vr_handle h, int dims3[3], float spacing3[3], int *datasize_byte
 int vr_get_dataset_range(vr_handle h, int *min_val, int *max_val);
 /* 256-bin display histogram (src/RendererCore.cpp:386-405) */
 int vr_histogram(vr_handle h, float hist256[256]);
+/* measurement aid (SURVEY 8d "confirm the HBM peak on the box"): best-of-reps streaming read of
+   the resident volume with 16-byte loads; *gbps = 1e9 bytes per second.  No reference
+   counterpart (the reference reads GL_TIME_ELAPSED only, src/RendererCore.cpp:149-153). */
+int vr_measure_stream_read(vr_handle h, int reps, double *gbps);
 
 /* ---- PVM / DDS codec (host only, no handle): readPVMvolume of the reference's
         include/ddsbase.h:29-35 (src/ddsbase.cpp:768-858).  Returns a malloc'ed payload of

@@ -90,6 +90,14 @@ def test_histogram_u16_matches_reference_formula(vra):
     assert np.allclose(h, want, rtol=1e-6)
 
 
+def test_stream_read_probe_reports_a_plausible_rate(vra):
+    """vr_measure_stream_read: the box's achievable HBM read rate, used by bench.py's roofline"""
+    with make(vra, (32, 32)) as r:
+        r.generateSynthetic(vra.renderer.SYNTH_NOISE_BALL, (512, 512, 512), 2, 1)     # 256 MiB
+        gbps = r.measureStreamRead(3)
+    assert 200.0 < gbps < 8000.0 * 1.05       # above PCIe-class rates, not above the HBM3E datasheet peak
+
+
 def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
     from PIL import Image
 

@@ -330,6 +330,30 @@ void RendererCore::computeHistogram(float out[256])
     }
 }
 
+double RendererCore::measureStreamRead(int reps)
+{
+    requireDevice("measureStreamRead");
+    if (!d_vol_) throw std::runtime_error("measureStreamRead: no dataset loaded");
+    const uint64_t bytes = (uint64_t)storageVoxels(tex3D_dim[0], tex3D_dim[1], tex3D_dim[2], vol_layout_) * (uint64_t)datasize_bytes & ~15ull;
+    hipEvent_t a = nullptr, b = nullptr;
+    check(hipEventCreate(&a), "hipEventCreate");
+    check(hipEventCreate(&b), "hipEventCreate");
+    double best_ms = 1e30;
+    hipError_t e = hipMemsetAsync(d_scratch_, 0, sizeof(unsigned), stream());
+    for (int r = 0; r < std::max(reps, 1) + 1 && e == hipSuccess; r++) {      // first pass warms up
+        e = hipEventRecord(a, stream());
+        if (e == hipSuccess) e = launch_stream_read(d_vol_, bytes, d_scratch_, stream());
+        if (e == hipSuccess) e = hipEventRecord(b, stream());
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (r > 0 && (double)ms < best_ms) best_ms = (double)ms;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    check(e, "stream_read_kernel");
+    return (double)bytes / (best_ms * 1e-3) / 1e9;
+}
+
 void RendererCore::afterVolumeLoaded(const std::string &name)
 {
     scanDatasetRange();

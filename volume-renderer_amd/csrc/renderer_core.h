@@ -83,6 +83,8 @@ public:
     void setFramebufferCompact(bool on) { fb_compact_ = on; }
     int localRows() const;   // rows this handle renders (stripe padding included)
     void computeHistogram(float out[256]);
+    // best-of-`reps` streaming read of the resident volume; returns GB/s (1e9 bytes per second)
+    double measureStreamRead(int reps);
     const char *lastKernelName() const { return last_kernel_; }
     bool hasDevice() const { return device_ >= 0; }
 

@@ -230,6 +230,14 @@ int vr_histogram(vr_handle h, float hist256[256])
     });
 }
 
+int vr_measure_stream_read(vr_handle h, int reps, double *gbps)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        if (!gbps) throw std::invalid_argument("vr_measure_stream_read: null result");
+        *gbps = c.measureStreamRead(reps);
+    });
+}
+
 int vr_set_alpha(vr_handle h, float alpha_scale)
 {
     return guarded(h, [&](vr::RendererCore &c) { c.alpha_scale = alpha_scale; c.setAlpha(); });   // RendererGUI.cpp:336-337

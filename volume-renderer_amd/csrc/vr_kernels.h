@@ -37,4 +37,7 @@ hipError_t launch_stats(const void *vol, int bytes_per_voxel, uint32_t nx, uint3
                         uint32_t bnx, uint32_t bny, int pass, float scale255, unsigned *d_minmax, unsigned *d_hist,
                         hipStream_t st);
 
+// streaming 16-byte reads of `bytes` bytes (bandwidth probe)
+hipError_t launch_stream_read(const void *p, uint64_t bytes, unsigned *sink, hipStream_t st);
+
 }  // namespace vr

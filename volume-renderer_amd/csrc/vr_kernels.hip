@@ -1400,6 +1400,25 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
     return hipGetLastError();
 }
 
+// streaming read of a device buffer with 16-byte loads: the box's achievable HBM read rate,
+// measured next to the ray-march (vr_measure_stream_read)
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16, unsigned *sink)
+{
+    uint32_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = p[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) atomicAdd(sink, 1u);   // keeps the loads alive; practically never taken
+}
+
+hipError_t launch_stream_read(const void *p, uint64_t bytes, unsigned *sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)p, bytes / 16u, sink);
+    return hipGetLastError();
+}
+
 hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st)
 {
     hipLaunchKernelGGL(certify_div_kernel, dim3((1u << 23) / 256u), dim3(256), 0, st, b, r, d_bad);

@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
         "vr_get_dims": (i32, [h, C.POINTER(i32), C.POINTER(f32), C.POINTER(i32)]),
         "vr_get_dataset_range": (i32, [h, C.POINTER(i32), C.POINTER(i32)]),
         "vr_histogram": (i32, [h, C.POINTER(f32)]),
+        "vr_measure_stream_read": (i32, [h, i32, C.POINTER(C.c_double)]),
         "vr_set_alpha": (i32, [h, f32]),
         "vr_set_mip": (i32, [h, i32]),
         "vr_set_view": (i32, [h, i32, i32]),
@@ -302,6 +303,12 @@ class RendererCore:
         out = np.zeros(256, dtype=np.float32)
         self._check(self._lib.vr_histogram(self._h, _fp(out)))
         return out
+
+    def measureStreamRead(self, reps: int = 5) -> float:
+        """achievable HBM read rate on this box (GB/s): streaming read of the resident volume"""
+        g = C.c_double()
+        self._check(self._lib.vr_measure_stream_read(self._h, reps, C.byref(g)))
+        return g.value
 
     # -- uniforms
     def setAlpha(self, alpha_scale):
