@@ -172,8 +172,13 @@ float vr_kernel_ms_take(vr_handle h);
 int vr_count_samples(vr_handle h, uint64_t *total, uint32_t *per_pixel, size_t n_pixels);
 void *vr_framebuffer_device(vr_handle h);
 int vr_read_pixels(vr_handle h, float *rgba, size_t n_floats);     /* D2H of the target */
-/* saveImage(fn, ext) (src/RendererCore.cpp:165-182): ext ".png" | ".bmp" | ".ppm" */
+/* saveImage(fn, ext) (src/RendererCore.cpp:165-182): ext ".png" | ".jpg" (quality 100, as
+   :177) | ".bmp" of the reference's dialog (RendererGUI.cpp:221), plus ".ppm" */
 int vr_save_image(vr_handle h, const char *path, const char *ext);
+/* the writers behind vr_save_image for an RGB8 image already in host memory (rows top first,
+   stride in bytes); host only, no handle.  Returns VR_OK or VR_E_IO / VR_E_INVALID. */
+int vr_write_image_rgb8(const char *path, const char *ext, int width, int height,
+                        const unsigned char *rgb, int stride_bytes);
 
 /* name of the kernel variant the last vr_render* launched (for profiles/tests) */
 const char *vr_last_kernel_name(vr_handle h);

@@ -159,3 +159,29 @@ def test_argument_validation(vra):
     lib = vra.load_library()
     assert lib.vr_render(None) == vra.renderer.VR_E_INVALID            # null handle
     assert lib.vr_create(None, -1) == vra.renderer.VR_E_INVALID
+
+
+def test_image_writers_host_only(vra, tmp_path):
+    """vr_write_image_rgb8: PNG/BMP/PPM are lossless; the baseline JPEG (quality 100, 4:4:4,
+    Annex K tables) decodes with an independent decoder to within a few levels.  Formats of
+    saveImage, src/RendererCore.cpp:173-178."""
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:61, 0:83]
+    img = np.stack([(xx * 3) % 256, (yy * 4) % 256, (xx + yy) % 256], axis=-1).astype(np.uint8)
+    img[20:40, 30:60] = rng.integers(0, 256, size=(20, 30, 3), dtype=np.uint8)      # noise patch: worst case for the DCT
+    for ext in (".png", ".bmp", ".ppm"):
+        assert vra.write_image_rgb8(tmp_path / f"a{ext}", ext, img)
+        assert np.array_equal(np.asarray(Image.open(tmp_path / f"a{ext}").convert("RGB")), img), ext
+    assert vra.write_image_rgb8(tmp_path / "a.jpg", ".jpg", img)
+    with Image.open(tmp_path / "a.jpg") as im:
+        assert im.format == "JPEG" and im.size == (83, 61)
+        got = np.asarray(im.convert("RGB")).astype(np.int32)
+    err = np.abs(got - img.astype(np.int32))
+    assert err.max() <= 6 and err.mean() < 1.0
+    # 1x1 and non-multiple-of-8 sizes, grey image
+    grey = np.full((1, 1, 3), 137, dtype=np.uint8)
+    assert vra.write_image_rgb8(tmp_path / "g.jpg", ".jpg", grey)
+    assert np.abs(np.asarray(Image.open(tmp_path / "g.jpg").convert("RGB")).astype(int) - 137).max() <= 1
+    assert not vra.write_image_rgb8(tmp_path / "a.gif", ".gif", img)

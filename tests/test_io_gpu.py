@@ -107,13 +107,15 @@ def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
         r.setAlpha(0.5)
         r.render()
         frame = r.readPixels()
-        for ext in (".png", ".bmp", ".ppm"):
+        for ext in (".png", ".bmp", ".ppm", ".jpg"):
             assert r.saveImage(tmp_path / f"shot{ext}", ext)
-        assert not r.saveImage(tmp_path / "shot.jpg", ".jpg")
+        assert not r.saveImage(tmp_path / "shot.gif", ".gif")
     want = np.floor(np.clip(frame[::-1, :, :3], 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)   # top row first
     for ext in (".png", ".bmp", ".ppm"):
         img = np.asarray(Image.open(tmp_path / f"shot{ext}").convert("RGB"))
         assert img.shape == (52, 77, 3) and np.array_equal(img, want), ext
+    jpg = np.asarray(Image.open(tmp_path / "shot.jpg").convert("RGB")).astype(np.int32)      # quality 100, 4:4:4
+    assert jpg.shape == (52, 77, 3) and np.abs(jpg - want.astype(np.int32)).max() <= 3
 
 
 def test_external_target_stream_and_compact_shard(vra, oracle):

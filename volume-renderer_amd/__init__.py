@@ -14,6 +14,7 @@ from .renderer import (  # noqa: F401
     VRError,
     build_library,
     checksum,
+    write_image_rgb8,
     load_library,
     read_pvm_volume,
     symbols_declared_in_header,
@@ -25,6 +26,7 @@ __all__ = [
     "VRError",
     "build_library",
     "checksum",
+    "write_image_rgb8",
     "load_library",
     "read_pvm_volume",
     "symbols_declared_in_header",

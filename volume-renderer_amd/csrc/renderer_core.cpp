@@ -788,7 +788,8 @@ bool RendererCore::saveImage(std::string fn, std::string ext)
     if (ext == ".png") return writePNG(fn, w, h, rgb.data(), stride);
     if (ext == ".bmp") return writeBMP(fn, w, h, rgb.data(), stride);
     if (ext == ".ppm") return writePPM(fn, w, h, rgb.data(), stride);
-    return false;   // ".jpg" (stb) is not provided
+    if (ext == ".jpg") return writeJPEG(fn, w, h, rgb.data(), stride, 100);   // :176-177
+    return false;
 }
 
 }  // namespace vr

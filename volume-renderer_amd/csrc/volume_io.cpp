@@ -338,6 +338,198 @@ bool writePPM(const std::string &path, int w, int h, const uint8_t *rgb, int str
     return bool(f);
 }
 
+// Baseline sequential JPEG (ITU-T T.81), 8-bit YCbCr 4:4:4, the Annex K example quantisation
+// and Huffman tables, IJG-style quality scaling -- what saveImage(".jpg") needs
+// (src/RendererCore.cpp:176-177 writes quality 100).  Written from the standard; rows are
+// taken in the order given.
+namespace {
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                             15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t kQuantLuma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57,
+                                69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55,
+                                64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQuantChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                  99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kDcLumaBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcChromaBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumaBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumaVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChromaBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcChromaVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22,
+    0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1,
+    0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+    0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a,
+    0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba,
+    0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+    0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct HuffCodes { uint16_t code[256]; uint8_t len[256]; };
+
+// canonical code assignment of T.81 Annex C
+HuffCodes buildHuff(const uint8_t bits[16], const uint8_t *vals)
+{
+    HuffCodes h = {};
+    uint16_t code = 0;
+    int k = 0;
+    for (int l = 1; l <= 16; l++) {
+        for (int i = 0; i < bits[l - 1]; i++, k++) { h.code[vals[k]] = code++; h.len[vals[k]] = (uint8_t)l; }
+        code <<= 1;
+    }
+    return h;
+}
+
+struct JpegBits {
+    std::vector<uint8_t> &out;
+    uint32_t acc = 0;
+    int n = 0;
+    void put(uint32_t v, int len)
+    {
+        acc = (acc << len) | (v & ((1u << len) - 1u));
+        n += len;
+        while (n >= 8) {
+            const uint8_t b = (uint8_t)(acc >> (n - 8));
+            out.push_back(b);
+            if (b == 0xff) out.push_back(0);      // byte stuffing
+            n -= 8;
+        }
+    }
+    void flush() { if (n > 0) put(0x7f, 8 - n); }   // pad with 1-bits
+};
+
+void jpegSegment(std::vector<uint8_t> &out, uint8_t marker, const std::vector<uint8_t> &body)
+{
+    out.push_back(0xff); out.push_back(marker);
+    const size_t len = body.size() + 2;
+    out.push_back((uint8_t)(len >> 8)); out.push_back((uint8_t)len);
+    out.insert(out.end(), body.begin(), body.end());
+}
+
+// separable 8x8 forward DCT-II with the JPEG normalisation (double precision)
+void fdct8x8(const double in[64], double outc[64])
+{
+    static double basis[8][8];
+    static bool init = false;
+    if (!init) {
+        for (int u = 0; u < 8; u++)
+            for (int x = 0; x < 8; x++)
+                basis[u][x] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        init = true;
+    }
+    double tmp[64];
+    for (int y = 0; y < 8; y++)
+        for (int u = 0; u < 8; u++) {
+            double a = 0.0;
+            for (int x = 0; x < 8; x++) a += basis[u][x] * in[y * 8 + x];
+            tmp[y * 8 + u] = a;
+        }
+    for (int v = 0; v < 8; v++)
+        for (int u = 0; u < 8; u++) {
+            double a = 0.0;
+            for (int y = 0; y < 8; y++) a += basis[v][y] * tmp[y * 8 + u];
+            outc[v * 8 + u] = a;
+        }
+}
+
+int bitLength(int v) { int n = 0; for (v = v < 0 ? -v : v; v; v >>= 1) n++; return n; }
+}  // namespace
+
+bool writeJPEG(const std::string &path, int w, int h, const uint8_t *rgb, int stride, int quality)
+{
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return false;
+    quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    uint8_t qt[2][64];
+    for (int i = 0; i < 64; i++) {
+        const int l = (kQuantLuma[i] * scale + 50) / 100, c = (kQuantChroma[i] * scale + 50) / 100;
+        qt[0][i] = (uint8_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
+        qt[1][i] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+    }
+    std::vector<uint8_t> out = {0xff, 0xd8};
+    jpegSegment(out, 0xe0, {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0});
+    for (int t = 0; t < 2; t++) {
+        std::vector<uint8_t> b = {(uint8_t)t};
+        for (int i = 0; i < 64; i++) b.push_back(qt[t][kZigzag[i]]);
+        jpegSegment(out, 0xdb, b);
+    }
+    jpegSegment(out, 0xc0, {8, (uint8_t)(h >> 8), (uint8_t)h, (uint8_t)(w >> 8), (uint8_t)w, 3,
+                            1, 0x11, 0, 2, 0x11, 1, 3, 0x11, 1});
+    auto dht = [&](uint8_t id, const uint8_t bits[16], const uint8_t *vals, int nvals) {
+        std::vector<uint8_t> b = {id};
+        b.insert(b.end(), bits, bits + 16);
+        b.insert(b.end(), vals, vals + nvals);
+        jpegSegment(out, 0xc4, b);
+    };
+    dht(0x00, kDcLumaBits, kDcVals, 12); dht(0x10, kAcLumaBits, kAcLumaVals, 162);
+    dht(0x01, kDcChromaBits, kDcVals, 12); dht(0x11, kAcChromaBits, kAcChromaVals, 162);
+    jpegSegment(out, 0xda, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+
+    const HuffCodes dc[2] = {buildHuff(kDcLumaBits, kDcVals), buildHuff(kDcChromaBits, kDcVals)};
+    const HuffCodes ac[2] = {buildHuff(kAcLumaBits, kAcLumaVals), buildHuff(kAcChromaBits, kAcChromaVals)};
+    JpegBits bw{out};
+    int pred[3] = {0, 0, 0};
+    for (int by = 0; by < h; by += 8)
+        for (int bx = 0; bx < w; bx += 8) {
+            double comp[3][64];
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) {
+                    const int sx = bx + x < w ? bx + x : w - 1, sy = by + y < h ? by + y : h - 1;   // edge replication
+                    const uint8_t *p = rgb + (size_t)sy * stride + (size_t)sx * 3;
+                    const double r = p[0], g = p[1], b = p[2];
+                    comp[0][y * 8 + x] = 0.299 * r + 0.587 * g + 0.114 * b - 128.0;
+                    comp[1][y * 8 + x] = -0.168735892 * r - 0.331264108 * g + 0.5 * b;
+                    comp[2][y * 8 + x] = 0.5 * r - 0.418687589 * g - 0.081312411 * b;
+                }
+            for (int c = 0; c < 3; c++) {
+                const int t = c == 0 ? 0 : 1;
+                double coef[64];
+                fdct8x8(comp[c], coef);
+                int q[64];
+                for (int i = 0; i < 64; i++) q[i] = (int)std::lround(coef[kZigzag[i]] / (double)qt[t][kZigzag[i]]);
+                // DC difference
+                const int diff = q[0] - pred[c];
+                pred[c] = q[0];
+                int nb = bitLength(diff);
+                bw.put(dc[t].code[nb], dc[t].len[nb]);
+                if (nb) bw.put((uint32_t)(diff < 0 ? diff - 1 : diff), nb);
+                // AC run lengths
+                int run = 0;
+                int last = 63;
+                while (last > 0 && q[last] == 0) last--;
+                for (int i = 1; i <= last; i++) {
+                    if (q[i] == 0) { run++; continue; }
+                    while (run > 15) { bw.put(ac[t].code[0xf0], ac[t].len[0xf0]); run -= 16; }
+                    nb = bitLength(q[i]);
+                    const int sym = (run << 4) | nb;
+                    bw.put(ac[t].code[sym], ac[t].len[sym]);
+                    bw.put((uint32_t)(q[i] < 0 ? q[i] - 1 : q[i]), nb);
+                    run = 0;
+                }
+                if (last < 63) bw.put(ac[t].code[0x00], ac[t].len[0x00]);   // EOB
+            }
+        }
+    bw.flush();
+    out.push_back(0xff); out.push_back(0xd9);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    return bool(f);
+}
+
 // =====================================================================  N3: spline
 // Natural cubic spline through (iso, rgba) knots: tridiagonal forward elimination /
 // back substitution per channel (src/CubicSpline.cpp:50-115), evaluated at integer

@@ -33,6 +33,8 @@ bool parsePVM(const std::vector<uint8_t> &raw, PvmVolume &out, std::string &err)
 bool writePNG(const std::string &path, int w, int h, const uint8_t *rgb, int stride_bytes);
 bool writeBMP(const std::string &path, int w, int h, const uint8_t *rgb, int stride_bytes);
 bool writePPM(const std::string &path, int w, int h, const uint8_t *rgb, int stride_bytes);
+// baseline JPEG, YCbCr 4:4:4, quality 1..100 (the reference writes 100, src/RendererCore.cpp:177)
+bool writeJPEG(const std::string &path, int w, int h, const uint8_t *rgb, int stride_bytes, int quality);
 
 // ---- N3: natural cubic spline transfer function (src/CubicSpline.cpp:13-115)
 // knots: iso[n] ascending in 0..255, rgba[n*4]; lut: 256 x RGBA clamped to [0,1]

@@ -405,6 +405,24 @@ int vr_save_image(vr_handle h, const char *path, const char *ext)
     return g != VR_OK ? g : rc;
 }
 
+int vr_write_image_rgb8(const char *path, const char *ext, int width, int height, const unsigned char *rgb,
+                        int stride_bytes)
+{
+    if (!path || !ext || !rgb || width <= 0 || height <= 0 || stride_bytes < width * 3) return VR_E_INVALID;
+    try {
+        const std::string e = ext;
+        bool ok = false;
+        if (e == ".png") ok = vr::writePNG(path, width, height, rgb, stride_bytes);
+        else if (e == ".jpg") ok = vr::writeJPEG(path, width, height, rgb, stride_bytes, 100);
+        else if (e == ".bmp") ok = vr::writeBMP(path, width, height, rgb, stride_bytes);
+        else if (e == ".ppm") ok = vr::writePPM(path, width, height, rgb, stride_bytes);
+        else return VR_E_INVALID;
+        return ok ? VR_OK : VR_E_IO;
+    } catch (...) {
+        return VR_E_IO;
+    }
+}
+
 unsigned char *vr_read_pvm_volume(const char *filename, unsigned int *width, unsigned int *height,
                                   unsigned int *depth, unsigned int *components, float *scalex, float *scaley,
                                   float *scalez)

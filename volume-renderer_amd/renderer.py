@@ -133,6 +133,7 @@ def load_library() -> C.CDLL:
         "vr_last_kernel_name": (C.c_char_p, [h]),
         "vr_read_pvm_volume": (C.c_void_p, [C.c_char_p] + [C.POINTER(C.c_uint)] * 4 + [C.POINTER(f32)] * 3),
         "vr_checksum": (C.c_uint, [C.c_void_p, C.c_uint]),
+        "vr_write_image_rgb8": (i32, [C.c_char_p, C.c_char_p, i32, i32, C.c_void_p, i32]),
         "vr_free": (None, [C.c_void_p]),
     }
     for name, (res, args) in sigs.items():
@@ -155,6 +156,13 @@ def read_pvm_volume(path):
     data = np.frombuffer((C.c_ubyte * n).from_address(p), dtype=np.uint8).copy()
     lib.vr_free(p)
     return data, (w.value, h.value, d.value, c.value), (sx.value, sy.value, sz.value)
+
+
+def write_image_rgb8(path, ext: str, rgb: np.ndarray) -> bool:
+    """the writers behind saveImage for an [H, W, 3] uint8 image (host only)"""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w = a.shape[:2]
+    return load_library().vr_write_image_rgb8(str(path).encode(), ext.encode(), w, h, a.ctypes.data, w * 3) == VR_OK
 
 
 def checksum(data: np.ndarray) -> int:
