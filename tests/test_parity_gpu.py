@@ -596,13 +596,17 @@ def _random_camera_block(rng, radius_lo=0.2, radius_hi=4.0):
     return b
 
 
-def test_randomised_cameras_volumes_and_modes(vra, oracle):
-    """stress of the safe-prefix / certified-division / batching logic: random dims (odd,
-    tiny, power-of-two), spacings, cameras (inside, grazing, axis-parallel), windows, alpha"""
-    rng = np.random.default_rng(20260928)
+def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
+    """randomised parity trials (3 cameras each); `extended` also draws MIP / transfer function /
+    TRILINEAR / closed-form accumulation / forced relay kernel / row stripes.  Used by the test
+    below and, with many more trials, by tools/stress_campaign.py.  Returns frames checked."""
+    rng = np.random.default_rng(seed)
     dims_pool = [(1, 1, 1), (2, 3, 5), (8, 8, 8), (16, 32, 64), (31, 17, 9), (64, 64, 64), (50, 1, 50), (128, 4, 4)]
+    if extended:
+        dims_pool += [(32, 32, 32), (7, 64, 33), (96, 80, 72), (4, 4, 128), (256, 16, 16)]
+    R = vra.renderer
     n_checked = 0
-    for trial in range(120):
+    for trial in range(n_trials):
         dims = dims_pool[trial % len(dims_pool)]
         dtype = np.uint8 if trial % 3 else np.uint16
         vol = rand_volume(rng, dims, dtype, smooth=bool(trial % 2))
@@ -611,6 +615,15 @@ def test_randomised_cameras_volumes_and_modes(vra, oracle):
         lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
         alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
+        mip = tf = tri = accum = relay = stripes = False
+        if extended:
+            mode = int(rng.integers(0, 12))
+            mip, tf, tri, accum = mode == 1, mode == 2, mode == 3, mode == 4
+            relay = mode in (5, 6)
+            stripes = mode == 7
+            if rng.random() < 0.2:
+                W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
+        tf_lut = None
         with make_renderer(vra, (W, H)) as r:
             r.setQuirks(0)
             r.setLayout(trial % 2)
@@ -621,6 +634,21 @@ def test_randomised_cameras_volumes_and_modes(vra, oracle):
             top, bottom = (trial % 7 == 3), (trial % 7 == 5)
             if top or bottom:
                 r.setInitialCameraRotation(top, bottom)
+            if mip:
+                r.setMIP(True)
+            if tf:
+                r.setTransferFunction([0, 90, 160, 255], [[0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
+                tf_lut = r.getTransferLut()
+            if tri:
+                r.setFilter(R.FILTER_TRILINEAR)
+            if accum:
+                r.setAccum(1)
+            if relay:
+                r.setKernelVariant(3)
+            rows = None
+            if stripes:
+                rows = (4, int(rng.integers(0, 3)), 3)
+                r.setRowStripes(*rows)
             for _ in range(3):
                 block = _random_camera_block(rng)
                 if rng.random() < 0.25:                       # axis-parallel rays (zero direction components)
@@ -630,11 +658,32 @@ def test_randomised_cameras_volumes_and_modes(vra, oracle):
                 got = r.readPixels()
                 _, spp = r.countSamples(per_pixel=True)
                 p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi,
-                                        view_top=int(top), view_bottom=int(bottom))
+                                        view_top=int(top), view_bottom=int(bottom), is_mip=int(mip), filter=int(tri),
+                                        accum=int(accum), tf_rgba=tf_lut)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
-                assert_same(got, want, spp, want_spp, what=f"trial {trial} dims {dims} spacing {spacing} kernel {r.last_kernel_name}")
+                what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} stripes {rows} kernel {r.last_kernel_name}")
+                if rows:                                       # only this shard's rows are rendered
+                    mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
+                    assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)
+                else:
+                    assert_same(got, want, spp, want_spp, what=what)
                 n_checked += 1
-    assert n_checked == 360
+        if log and (trial + 1) % 200 == 0:
+            log(f"{trial + 1} trials, {n_checked} frames bit-exact")
+    return n_checked
+
+
+def test_randomised_cameras_volumes_and_modes(vra, oracle):
+    """stress of the safe-prefix / certified-division / batching logic: random dims (odd,
+    tiny, power-of-two), spacings, cameras (inside, grazing, axis-parallel), windows, alpha"""
+    assert run_random_trials(vra, oracle, 20260928, 120) == 360
+
+
+def test_randomised_extended_modes(vra, oracle):
+    """the same with MIP / transfer function / TRILINEAR / closed-form accumulation / forced
+    relay kernel / row stripes drawn at random (tools/stress_campaign.py runs thousands)"""
+    assert run_random_trials(vra, oracle, 7, 96, extended=True) == 288
 
 
 def test_out_of_contract_parameters_fall_back_to_the_generic_kernel(vra, oracle):
