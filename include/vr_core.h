@@ -139,6 +139,10 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    1 = always the generic line-by-line kernel (cross-check / debugging), 2 = automatic but never
    the relay kernel, 3 = automatic but always the relay kernel when the shape allows */
 int vr_set_kernel_variant(vr_handle h, int variant);
+/* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
+   specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %
+   fewer cache lines per frame; frames are bit-identical); 0: never.  Build-defined. */
+int vr_set_pack12(vr_handle h, int enable);
 /* 1-D transfer function (N3): n knots of (iso in 0..255, r,g,b,a); n = 0 restores the
    reference grey ramp.  Built with the natural cubic spline of src/CubicSpline.cpp. */
 int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n);

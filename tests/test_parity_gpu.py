@@ -596,6 +596,49 @@ def _random_camera_block(rng, radius_lo=0.2, radius_hi=4.0):
     return b
 
 
+def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle):
+    """vr_set_pack12: a bricked u16 volume whose voxels are all <= 4095 is gathered from a 12-bit
+    packed copy (unaligned 2-byte loads, some straddling cache lines); frames must equal the
+    oracle and the unpacked path bit for bit.  Volumes with a larger voxel never use it."""
+    rng = np.random.default_rng(12)
+    R = vra.renderer
+    for dims in ((64, 64, 64), (37, 21, 50), (128, 8, 16), (5, 3, 2)):
+        vol = rand_volume(rng, dims, np.uint16)                  # values 0..4095: eligible
+        vol.flat[0] = 4095; vol.flat[-1] = 0
+        frames = {}
+        for pack in (1, 0):
+            with make_renderer(vra, (96, 80)) as r:
+                r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED); r.setPack12(pack)
+                r.setVolume(vol); r.setWindow(0, 4095); r.setAlpha(0.05)
+                r.cameraOrient(0.0, -0.4, 0.9)
+                block = r.getCameraBlock()
+                r.render()
+                frames[pack] = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                assert r.last_kernel_name in FAST_KERNELS
+        want, _, want_spp = oracle.render(vol, oracle.OracleParams(96, 80, cam=block, alpha_scale=0.05, min_val=0, max_val=4095), want_spp=True)
+        assert_same(frames[1], want, spp, want_spp, what=f"packed12 dims {dims}")
+        assert np.array_equal(frames[1].view(np.uint32), frames[0].view(np.uint32)), dims
+    # one voxel above 4095: the packed copy must not be used (it would truncate)
+    vol = rand_volume(rng, (32, 32, 32), np.uint16)
+    vol[7, 9, 11] = 60000
+    with make_renderer(vra, (64, 64)) as r:
+        r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED); r.setVolume(vol); r.setWindow(0, 65535); r.setAlpha(0.3)
+        r.render()
+        got = r.readPixels()
+    want, _ = oracle.render(vol, oracle.OracleParams(64, 64, alpha_scale=0.3, min_val=0, max_val=65535))
+    assert_same(got, want, what="u16 volume with a voxel > 4095")
+
+
+def test_packed12_full_size_equals_unpacked(cfg3):
+    """cfg3 (1024^3 u16 @1080p): packed and unpacked gathers give the same frame"""
+    r = cfg3
+    r.setPack12(1); r.render(); a = r.readPixels().copy()
+    r.setPack12(0); r.render(); b = r.readPixels().copy()
+    r.setPack12(1)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
     """randomised parity trials (3 cameras each); `extended` also draws MIP / transfer function /
     TRILINEAR / closed-form accumulation / forced relay kernel / row stripes.  Used by the test

@@ -91,6 +91,7 @@ public:
     int filter = 0, accum = 0, layout = 0, skip_empty = 0;
     uint32_t quirks = 2u;   // VR_QUIRK_DEFAULT
     int force_generic = 0;
+    int pack12 = 1;                          // 1: keep a 12-bit packed copy for the fast kernel when the data allow (vr_set_pack12)
     int tile_order = 1;      // 1: longest-first tile schedule, 0: arithmetic order
     std::string last_error;
 
@@ -123,6 +124,9 @@ private:
     bool fb_compact_ = false;
     std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
+    void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)
+    size_t vol12_bytes_ = 0;
+    void refreshPacked12(const FrameParams &P, LaunchConfig &L);
     size_t skip_grid_cells_ = 0;
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)

@@ -316,6 +316,11 @@ int vr_set_kernel_variant(vr_handle h, int variant)
     });
 }
 
+int vr_set_pack12(vr_handle h, int enable)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.pack12 = enable != 0; });
+}
+
 int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n)
 {
     return guarded(h, [&](vr::RendererCore &c) { c.setTransferFunction(iso, rgba4, n); });

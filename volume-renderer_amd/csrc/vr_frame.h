@@ -69,6 +69,8 @@ struct LaunchConfig {
     int sparse_shard;              // use the 4-wavefront relay kernel when the shape allows
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;
+    const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
+    uint32_t packed12_bytes;
 };
 
 }  // namespace vr

@@ -183,6 +183,10 @@ __device__ __forceinline__ int floor_to_int_sat(float f)
 // for e in [0, max_val-min_val] in LDS with the shader's own operations (so entries are
 // bit-identical to the per-sample computation) and a sample then costs one ds_read_b64.
 constexpr int FAST_LUT_MAX = 4096;      // entries (x 8 B = 32 KiB of the CU's 160 KiB LDS)
+// Address tables (ATAB): the byte offset of voxel (i,j,k) is X[i] + Y[j] + Z[k] in both layouts,
+// so the ~10 integer VALU ops of VoxelAddr become three LDS look-ups and one add; integer ops
+// issue at ~1.6x the cost of fp32 ops on gfx950 and are 40 % of the inner loop's issue time.
+constexpr int FAST_AXIS_TAB_MAX = 3072; // entries: nx + ny + nz (x 4 B = 12 KiB)
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c)
 {
@@ -471,7 +475,7 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // SKIPT: empty-space skipping compiled in (its probe state costs ~18 VGPRs = one workgroup
 // of occupancy per CU, so the headline variant is also built without it).
 // BATCH: samples per gather batch (8: the skip grid's dilation covers exactly that).
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH, bool ATAB, bool PK12>
 #ifndef VR_EXP_FAST_OCC          // experiment knobs: waves per SIMD asked of the compiler, batch length
 #define VR_EXP_FAST_OCC 1
 #endif
@@ -488,11 +492,16 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
                                                             const unsigned chunks_per_row,
                                                             const uint32_t *__restrict__ tile_table,
                                                             const uint16_t *__restrict__ skip_grid,
-                                                            const uint32_t skip_grid_bytes)
+                                                            const uint32_t skip_grid_bytes,
+                                                            const void *__restrict__ packed12,
+                                                            const uint32_t packed12_bytes)
 {
     static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
+    static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH == 8), "12-bit copy: u16 bricks through the address tables");
     constexpr int LUT_STRIDE = MODE == 2 ? 4 : 2;          // floats per entry
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
+    __shared__ uint32_t axis_tab[ATAB ? FAST_AXIS_TAB_MAX : 1];
+    static_assert(!ATAB || !BIG, "address tables hold 32-bit byte offsets");
 #ifdef VR_EXP_TRACE             // experiment only: per-wave start/end timestamps into spp
     const unsigned long long trace_t0 = wall_clock64();
 #endif
@@ -529,10 +538,32 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
         hit = intersect_ray_aabb(P, ray, t_min, t_max);
     }
-    if (LUT) {
+    if (LUT || ATAB) {
         // tabulate only if some ray of the workgroup enters the volume
         if (__syncthreads_or(hit ? 1 : 0)) {
-            const int n = P.max_val - P.min_val + 1;
+            if (ATAB) {
+                // per-axis terms of VoxelAddr<LAYOUT, false>::at, in bytes.  PK12: the Y and Z terms are
+                // multiples of BRICK_X (even), so floor(1.5*(x + y + z)) = floor(1.5*x) + 1.5*y + 1.5*z
+                const int na = P.nx + P.ny + P.nz;
+                for (int e = (int)threadIdx.x; e < na; e += (int)FAST_THREADS) {
+                    uint32_t t;
+                    if (e < P.nx) {
+                        const uint32_t i = (uint32_t)e;
+                        t = LAYOUT == 0 ? i : i + (64u - (uint32_t)BRICK_X) * (i >> BRICK_LX);
+                    } else if (e < P.nx + P.ny) {
+                        const uint32_t j = (uint32_t)(e - P.nx);
+                        t = LAYOUT == 0 ? j * (uint32_t)P.nx
+                                        : (BRICK_LY ? (j << BRICK_LX) + P.bstride_y * (j >> BRICK_LY) : P.bstride_y * j);
+                    } else {
+                        const uint32_t k = (uint32_t)(e - P.nx - P.ny);
+                        t = LAYOUT == 0 ? k * (uint32_t)P.ny * (uint32_t)P.nx
+                                        : (BRICK_LZ ? (k << (BRICK_LX + BRICK_LY)) + P.bstride_z * (k >> BRICK_LZ) : P.bstride_z * k);
+                    }
+                    axis_tab[e] = PK12 ? (uint32_t)((3ull * (uint64_t)t) >> 1)     // floor(1.5 * element offset): 12-bit voxels
+                                       : t * (uint32_t)sizeof(VoxelT);
+                }
+            }
+            const int n = LUT ? P.max_val - P.min_val + 1 : 0;
             for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
                 const float v = div_cert(s - P.fmin, P.fden, P.rden);
@@ -557,6 +588,9 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     uint32_t fetches = 0;
     {                                   // every thread runs the (barrier-carrying) batch loop
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)vol_bytes, 0x00020000);
+        // PK12: the prefix gathers from the 12-bit packed copy of the bricked volume (voxel with
+        // storage index s = bits [12s, 12s+12) of the stream: 25 % fewer cache lines per frame)
+        const __amdgpu_buffer_rsrc_t rs12 = __builtin_amdgcn_make_buffer_rsrc((void *)packed12, 0, (int)packed12_bytes, 0x00020000);
         const float EPSILON = 0.000001f;
         const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
         float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
@@ -641,9 +675,10 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         };
         uint32_t cell_next = 0xffffffffu;       // probe result for the next batch to be issued
         int k_issue = 0;                        // index of the first sample of the next batch to be issued
+        const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + (ATAB ? P.nx : 0), *tab_z = axis_tab + (ATAB ? P.nx + P.ny : 0);
         // gathers of one batch: BATCH consecutive samples from the current position;
         // returns true when the batch is skipped (positions still advance, bit-exactly)
-        auto issue = [&](uint32_t (&v)[BATCH]) -> bool {
+        auto issue = [&](uint32_t (&v)[BATCH], uint32_t &nib) -> bool {   // nib (PK12): bit offset (0 / 4) of sample u in nibble u
             bool skip = false;
             if (skip_on) {
                 skip = (int)cell_next <= P.skip_thresh;
@@ -674,14 +709,28 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
                     voxel_of(qx, qy, qz, vi, vj, vk);
                     qx += dsx; qy += dsy; qz += dsz;
                 }
-                off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
+                if (ATAB) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)(tab_x[vi] + tab_y[vj] + tab_z[vk]);   // bytes
+                else off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
+                if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);   // odd x: upper 12 of the 16 bits
             }
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
+                if (ATAB) {
+#if defined(VR_EXP_NOLOAD)
+                    v[u] = (uint32_t)(off[u] & 4095u);
+#else
+#if defined(VR_EXP_MASK)
+                    off[u] &= VR_EXP_MASK;
+#endif
+                    v[u] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[u], 0, 0)
+                                               : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rs, (int)off[u], 0, 0);
+#endif
+                    continue;
+                }
 #if defined(VR_EXP_NOLOAD)      // experiment only: no memory access at all (VALU bound)
                 v[u] = (uint32_t)(off[u] & 4095u);
 #elif defined(VR_EXP_MASK)      // experiment only: fold all accesses into 1 MiB (cache-resident)
-                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u] & 0x7FFFFu);
+                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u] & (VR_EXP_MASK >> 1));
 #else
                 v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
 #endif
@@ -705,7 +754,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
                 da += a * om;
             }
         };
-        auto consume = [&](const uint32_t (&v)[BATCH], bool skipped) -> bool {
+        auto consume = [&](const uint32_t (&v)[BATCH], bool skipped, uint32_t nib) -> bool {
             if (skipped) { i += BATCH; return false; }   // every sample of the batch adds exactly zero
             float c[BATCH], cg[BATCH], cb[BATCH], a[BATCH];
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
@@ -714,9 +763,9 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
             // latency hides behind the first half's dependent compositing chain
             constexpr int HALF = BATCH / 2;
 #pragma unroll
-            for (int u = 0; u < HALF; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
+            for (int u = 0; u < HALF; u++) classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
 #pragma unroll
-            for (int u = HALF; u < BATCH; u++) classify(v[u], c[u], cg[u], cb[u], a[u]);
+            for (int u = HALF; u < BATCH; u++) classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (u == BATCH - 1) da_last = da;
@@ -742,23 +791,24 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
             uint32_t va[BATCH], vb[BATCH];
+            uint32_t nib_a = 0, nib_b = 0;
             bool skip_a = false, skip_b = false;
             int b = 0;
             bool fin = nb == 0;
             if (!fin) {
                 if (skip_on) cell_next = probe(0);
-                skip_a = issue(va);
+                skip_a = issue(va, nib_a);
             }
             for (;;) {
                 if (__syncthreads_and(fin ? 1 : 0)) break;
                 if (!fin) {
-                    if (b + 1 < nb) skip_b = issue(vb);
-                    if (consume(va, skip_a)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_b = issue(vb, nib_b);
+                    if (consume(va, skip_a, nib_a)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
                 if (!fin) {
-                    if (b + 1 < nb) skip_a = issue(va);
-                    if (consume(vb, skip_b)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_a = issue(va, nib_a);
+                    if (consume(vb, skip_b, nib_b)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
             }
@@ -1267,15 +1317,16 @@ static hipError_t launch_generic(const FrameParams &P, const LaunchConfig &L, co
     return hipGetLastError();
 }
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH, bool ATAB, bool PK12>
 static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                               uint32_t *spp, int rows, hipStream_t st)
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH>), dim3(blocks),
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH, ATAB, PK12>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
-                       g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes);
+                       g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes,
+                       PK12 ? L.packed12 : nullptr, PK12 ? L.packed12_bytes : 0u);
     return hipGetLastError();
 }
 
@@ -1327,9 +1378,16 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     // the skipping-free build exists for the headline shape only (MODE 0, default view)
     constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
+    // LDS address tables: headline shape only (compile time), 32-bit offsets, nx + ny + nz entries fit;
+    // the 12-bit packed copy (host: refreshPacked12) rides on them
+    const bool atab = HEADLINE && !BIG && noskip && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
+    constexpr bool CAN_ATAB = HEADLINE && !BIG, CAN_PK12 = CAN_ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1;
+    const bool pk12 = atab && CAN_PK12 && L.packed12 != nullptr;
 #define VR_LAUNCH(TC, LT, P2, NC)                                                                                         \
-    (noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8>(P, L, vol, tf, fb, spp, rows, st) \
-            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true, 8>(P, L, vol, tf, fb, spp, rows, st))
+    (pk12 ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, CAN_ATAB, CAN_PK12>(P, L, vol, tf, fb, spp, rows, st) \
+     : atab ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, CAN_ATAB, false>(P, L, vol, tf, fb, spp, rows, st) \
+     : noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, false, false>(P, L, vol, tf, fb, spp, rows, st) \
+            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true, 8, false, false>(P, L, vol, tf, fb, spp, rows, st))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
         if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
@@ -1361,7 +1419,13 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
                                 float4 *fb, uint32_t *spp, int rows, hipStream_t st)
 {
     if constexpr (sizeof(VoxelT) == 2 && LAYOUT == 1)
-        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH>(P, L, vol, tf, fb, spp, rows, st);
+        #ifdef VR_EXP_NOATAB
+        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, false, false>(P, L, vol, tf, fb, spp, rows, st);
+#else
+        if (L.packed12)
+            return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, true, true>(P, L, vol, tf, fb, spp, rows, st);
+        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, true, false>(P, L, vol, tf, fb, spp, rows, st);
+#endif
     return hipErrorInvalidValue;
 }
 #else
@@ -1443,6 +1507,28 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
         hipLaunchKernelGGL(cellmax_kernel<uint16_t>, dim3(blocks_a), dim3(256), 0, st, (const uint16_t *)vol, tmp, nx, ny, nz,
                            layout, bnx, bny, cnx, cny, cnz);
     hipLaunchKernelGGL(dilate_kernel, dim3(blocks_b), dim3(256), 0, st, tmp, out, (int)cnx, (int)cny, (int)cnz);
+    return hipGetLastError();
+}
+
+// 12-bit packed copy of a u16 volume whose voxels are all <= 4095: voxel with storage index s
+// occupies bits [12s, 12s + 12) of a little-endian bit stream (8 voxels -> 3 dwords).  Any
+// storage order works; the fast kernel reads the bricked one (PK12).
+__global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ dst, uint64_t ngroups)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
+        const uint4 q = src[g];
+        const uint32_t v0 = q.x & 0xfffu, v1 = (q.x >> 16) & 0xfffu, v2 = q.y & 0xfffu, v3 = (q.y >> 16) & 0xfffu;
+        const uint32_t v4 = q.z & 0xfffu, v5 = (q.z >> 16) & 0xfffu, v6 = q.w & 0xfffu, v7 = (q.w >> 16) & 0xfffu;
+        dst[3 * g + 0] = v0 | (v1 << 12) | (v2 << 24);
+        dst[3 * g + 1] = (v2 >> 8) | (v3 << 4) | (v4 << 16) | (v5 << 28);
+        dst[3 * g + 2] = (v5 >> 4) | (v6 << 8) | (v7 << 20);
+    }
+}
+
+hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack12_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src_u16, (uint32_t *)dst, voxels / 8u);
     return hipGetLastError();
 }
 

@@ -114,6 +114,7 @@ def load_library() -> C.CDLL:
         "vr_set_layout": (i32, [h, i32]),
         "vr_set_skip_empty": (i32, [h, i32]),
         "vr_set_kernel_variant": (i32, [h, i32]),
+        "vr_set_pack12": (i32, [h, i32]),
         "vr_set_transfer_function": (i32, [h, C.POINTER(C.c_int32), C.POINTER(f32), i32]),
         "vr_get_transfer_lut": (i32, [h, C.POINTER(f32)]),
         "vr_set_row_range": (i32, [h, i32, i32]),
@@ -355,6 +356,9 @@ class RendererCore:
 
     def setKernelVariant(self, variant):
         self._check(self._lib.vr_set_kernel_variant(self._h, variant))
+
+    def setPack12(self, on):
+        self._check(self._lib.vr_set_pack12(self._h, int(bool(on))))
 
     def setTransferFunction(self, iso=None, rgba=None):
         if iso is None or len(iso) == 0:
