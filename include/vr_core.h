@@ -135,7 +135,7 @@ int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*              
 int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_*; re-lays the volume out */
 int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
 /* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches
-   of the headline shape that cannot fill the chip once use the 4-wavefront relay kernel),
+   of the headline shape with fewer than 256 active 32x16 tiles use the 4-wavefront relay kernel),
    1 = always the generic line-by-line kernel (cross-check / debugging), 2 = automatic but never
    the relay kernel, 3 = automatic but always the relay kernel when the shape allows */
 int vr_set_kernel_variant(vr_handle h, int variant);

@@ -724,11 +724,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
-    // 8 wavefronts per active 32x16 tile against 256 CUs x 32 wave slots: a launch that cannot
-    // fill the chip once is latency-bound per ray -> relay kernel.  Measured under sustained
-    // back-to-back launches: relay wins for the shards of N >= 2 GPUs (0.35/0.18/0.10 ms vs
-    // 0.37/0.21/0.18 ms at N = 2/4/8), the lockstep fast kernel for the full frame (0.61 vs 0.64)
-    L.sparse_shard = (tile_active_ * 8u < 8192u) ? 1 : 0;
+    // 8 wavefronts per active 32x16 tile against 256 CUs x 32 wave slots: a launch far from
+    // filling the chip is latency-bound per ray -> relay kernel.  Measured on cfg3 shards (both
+    // kernels with address tables + packed copy): fast / relay = 0.30 / 0.36 ms at N = 2 (685
+    // active tiles), 0.19 / 0.20 at N = 4 (342), 0.17 / 0.11 at N = 8 (171), 0.51 / 0.67 full frame
+    L.sparse_shard = (tile_active_ < 256u) ? 1 : 0;
     if (force_generic == 2) L.sparse_shard = 0;          // kernel variant 2: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
 }

@@ -157,6 +157,32 @@ __device__ __forceinline__ int floor_to_int_sat(float f)
     return (int)f;
 }
 
+// Per-axis address tables (ATAB): tab[0..nx) = X, tab[nx..nx+ny) = Y, tab[nx+ny..) = Z with
+// X[i] + Y[j] + Z[k] = byte offset of voxel (i,j,k) = sizeof(VoxelT) * VoxelAddr<LAYOUT,false>::at.
+// PK12 (12-bit packed copy): the Y and Z element terms are multiples of BRICK_X (even), so
+// floor(1.5*(x + y + z)) = floor(1.5*x) + 1.5*y + 1.5*z.  Called by all threads of a workgroup.
+template <typename VoxelT, int LAYOUT, bool PK12>
+__device__ __forceinline__ void build_axis_tables(const FrameParams &P, uint32_t *tab, int nthreads)
+{
+    const int na = P.nx + P.ny + P.nz;
+    for (int e = (int)threadIdx.x; e < na; e += nthreads) {
+        uint32_t t;
+        if (e < P.nx) {
+            const uint32_t i = (uint32_t)e;
+            t = LAYOUT == 0 ? i : i + (64u - (uint32_t)BRICK_X) * (i >> BRICK_LX);
+        } else if (e < P.nx + P.ny) {
+            const uint32_t j = (uint32_t)(e - P.nx);
+            t = LAYOUT == 0 ? j * (uint32_t)P.nx
+                            : (BRICK_LY ? (j << BRICK_LX) + P.bstride_y * (j >> BRICK_LY) : P.bstride_y * j);
+        } else {
+            const uint32_t k = (uint32_t)(e - P.nx - P.ny);
+            t = LAYOUT == 0 ? k * (uint32_t)P.ny * (uint32_t)P.nx
+                            : (BRICK_LZ ? (k << (BRICK_LX + BRICK_LY)) + P.bstride_z * (k >> BRICK_LZ) : P.bstride_z * k);
+        }
+        tab[e] = PK12 ? (uint32_t)((3ull * (uint64_t)t) >> 1) : t * (uint32_t)sizeof(VoxelT);
+    }
+}
+
 // ------------------------------------------------------------------ fast kernel
 // NEAREST + composite + iterative accumulation + grey ramp: the reference's own
 // configuration, and the one BASELINE.json's metric is quoted on.
@@ -541,28 +567,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     if (LUT || ATAB) {
         // tabulate only if some ray of the workgroup enters the volume
         if (__syncthreads_or(hit ? 1 : 0)) {
-            if (ATAB) {
-                // per-axis terms of VoxelAddr<LAYOUT, false>::at, in bytes.  PK12: the Y and Z terms are
-                // multiples of BRICK_X (even), so floor(1.5*(x + y + z)) = floor(1.5*x) + 1.5*y + 1.5*z
-                const int na = P.nx + P.ny + P.nz;
-                for (int e = (int)threadIdx.x; e < na; e += (int)FAST_THREADS) {
-                    uint32_t t;
-                    if (e < P.nx) {
-                        const uint32_t i = (uint32_t)e;
-                        t = LAYOUT == 0 ? i : i + (64u - (uint32_t)BRICK_X) * (i >> BRICK_LX);
-                    } else if (e < P.nx + P.ny) {
-                        const uint32_t j = (uint32_t)(e - P.nx);
-                        t = LAYOUT == 0 ? j * (uint32_t)P.nx
-                                        : (BRICK_LY ? (j << BRICK_LX) + P.bstride_y * (j >> BRICK_LY) : P.bstride_y * j);
-                    } else {
-                        const uint32_t k = (uint32_t)(e - P.nx - P.ny);
-                        t = LAYOUT == 0 ? k * (uint32_t)P.ny * (uint32_t)P.nx
-                                        : (BRICK_LZ ? (k << (BRICK_LX + BRICK_LY)) + P.bstride_z * (k >> BRICK_LZ) : P.bstride_z * k);
-                    }
-                    axis_tab[e] = PK12 ? (uint32_t)((3ull * (uint64_t)t) >> 1)     // floor(1.5 * element offset): 12-bit voxels
-                                       : t * (uint32_t)sizeof(VoxelT);
-                }
-            }
+            if (ATAB) build_axis_tables<VoxelT, LAYOUT, PK12>(P, axis_tab, (int)FAST_THREADS);
             const int n = LUT ? P.max_val - P.min_val + 1 : 0;
             for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
@@ -894,15 +899,19 @@ struct RelayState {
     unsigned final_n;      // the state slot holding the result is final_n & 1
 };
 
-template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP>
+template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP, bool ATAB, bool PK12>
 __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const FrameParams P,
                                                              const VoxelT *__restrict__ vol,
                                                              const uint32_t vol_bytes,
                                                              float4 *__restrict__ fb,
                                                              uint32_t *__restrict__ spp,
-                                                             const uint32_t *__restrict__ tile_table)
+                                                             const uint32_t *__restrict__ tile_table,
+                                                             const void *__restrict__ packed12,
+                                                             const uint32_t packed12_bytes)
 {
+    static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1), "12-bit copy: u16 bricks through the address tables");
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];
+    __shared__ uint32_t axis_tab[ATAB ? FAST_AXIS_TAB_MAX : 1];
     __shared__ RelayState rs_all[RELAY_TILES];
     // block b -> (32x16 tile of the longest-first table, pair of 8x8 sub-tiles); the 4 pairs of
     // a tile are consecutive blocks of ONE XCD (b & 7 is the XCD)
@@ -941,11 +950,14 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
         }
     }
+    if (ATAB && any_hit) build_axis_tables<VoxelT, LAYOUT, PK12>(P, axis_tab, RELAY_THREADS);
     if (w == 0) { rs.rgb[0][lane] = 0.0f; rs.a[0][lane] = 0.0f; rs.i[0][lane] = 0; }
     if (w == 0 && lane == 0) { rs.seq = 0u; rs.pseq = 0u; rs.stop = 0u; rs.final_n = 0u; }
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs12 = __builtin_amdgcn_make_buffer_rsrc((void *)packed12, 0, (int)packed12_bytes, 0x00020000);
+    const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + (ATAB ? P.nx : 0), *tab_z = axis_tab + (ATAB ? P.nx + P.ny : 0);
     const float EPSILON = 0.000001f;
     const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
     float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
@@ -985,7 +997,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         return true;
     };
     // gathers of batch n (if this ray still needs them); returns whether v[] is valid
-    auto issue = [&](int n, uint32_t (&v)[RELAY_BATCH], float da_seen) -> bool {
+    auto issue = [&](int n, uint32_t (&v)[RELAY_BATCH], uint32_t &nib, float da_seen) -> bool {
         float x = 0.0f, y = 0.0f, z = 0.0f;
         if (stopped || !take_position(n, x, y, z)) { stopped = true; return false; }
         const bool need = n < nb && da_seen < 0.95f;
@@ -1003,7 +1015,9 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
                     uz = 1.0f - uz;
                     vi = (int)(ux * P.fdim[0]); vj = (int)(uy * P.fdim[1]); vk = (int)(uz * P.fdim[2]);
                 }
-                off[u] = VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk);
+                if (ATAB) off[u] = tab_x[vi] + tab_y[vj] + tab_z[vk];                    // bytes
+                else off[u] = VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk);
+                if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);
                 x += mx; y += my; z += mz;
             }
         }
@@ -1012,7 +1026,13 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         if (lane == 0) __hip_atomic_store(&rs.pseq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (need) {
 #pragma unroll
-            for (int u = 0; u < RELAY_BATCH; u++) v[u] = VoxelFetch<VoxelT, false>::load(vol, rsrc, off[u]);
+            for (int u = 0; u < RELAY_BATCH; u++) {
+                if (ATAB)
+                    v[u] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsrc, (int)off[u], 0, 0)
+                                               : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rsrc, (int)off[u], 0, 0);
+                else
+                    v[u] = VoxelFetch<VoxelT, false>::load(vol, rsrc, off[u]);
+            }
         }
         return need;
     };
@@ -1032,11 +1052,12 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     };
     float da_seen = 0.0f;
     // take over the recurrence for batch n, composite, hand it on
-    auto relay = [&](int n, const uint32_t (&v)[RELAY_BATCH], bool valid) {
+    auto relay = [&](int n, const uint32_t (&v)[RELAY_BATCH], uint32_t nib, bool valid) {
         float c[RELAY_BATCH], a[RELAY_BATCH];
         if (valid) {
 #pragma unroll
-            for (int u = 0; u < RELAY_BATCH; u++) classify(v[u], c[u], a[u]);
+            for (int u = 0; u < RELAY_BATCH; u++)
+                classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], a[u]);
         }
         if (stopped || !wait_for(&rs.seq, n)) { stopped = true; return; }
         const int slot = n & 1;
@@ -1083,16 +1104,17 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
 
     {
         uint32_t va[RELAY_BATCH], vb[RELAY_BATCH];
+        uint32_t nib_a = 0, nib_b = 0;
         bool ok_a = false, ok_b = false;
         int n = (int)w;
-        if (n < nbmax) ok_a = issue(n, va, da_seen);
+        if (n < nbmax) ok_a = issue(n, va, nib_a, da_seen);
         while (n < nbmax && !stopped) {
-            if (n + RELAY_WAVES < nbmax) ok_b = issue(n + RELAY_WAVES, vb, da_seen);
-            relay(n, va, ok_a);
+            if (n + RELAY_WAVES < nbmax) ok_b = issue(n + RELAY_WAVES, vb, nib_b, da_seen);
+            relay(n, va, nib_a, ok_a);
             n += RELAY_WAVES;
             if (n >= nbmax || stopped) break;
-            if (n + RELAY_WAVES < nbmax) ok_a = issue(n + RELAY_WAVES, va, da_seen);
-            relay(n, vb, ok_b);
+            if (n + RELAY_WAVES < nbmax) ok_a = issue(n + RELAY_WAVES, va, nib_a, da_seen);
+            relay(n, vb, nib_b, ok_b);
             n += RELAY_WAVES;
         }
     }
@@ -1346,11 +1368,21 @@ static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, co
     const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
     const dim3 grid(L.tile_table_blocks * (8u / RELAY_TILES)), block(RELAY_THREADS);
+    const bool atab = P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
+    constexpr bool CAN_PK12 = sizeof(VoxelT) == 2 && LAYOUT == 1;
+    const bool pk12 = atab && CAN_PK12 && L.packed12 != nullptr;
+#define VR_RELAY2(TC, LT, P2, NC, AT, PK)                                                                         \
+    do {                                                                                                          \
+        hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC, AT, PK>), grid, block, 0, st, P,  \
+                           (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table,                     \
+                           (PK) ? L.packed12 : nullptr, (PK) ? L.packed12_bytes : 0u);                             \
+        return hipGetLastError();                                                                                 \
+    } while (0)
 #define VR_RELAY(TC, LT, P2, NC)                                                                                  \
     do {                                                                                                          \
-        hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC>), grid, block, 0, st, P,         \
-                           (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table);                    \
-        return hipGetLastError();                                                                                 \
+        if (pk12) VR_RELAY2(TC, LT, P2, NC, true, CAN_PK12);                                                      \
+        if (atab) VR_RELAY2(TC, LT, P2, NC, true, false);                                                         \
+        VR_RELAY2(TC, LT, P2, NC, false, false);                                                                  \
     } while (0)
     if (L.divmode_tc == DIV_CERT) {
         if (lut) { if (noclamp) VR_RELAY(DIV_CERT, true, false, true); else VR_RELAY(DIV_CERT, true, false, false); }
@@ -1362,6 +1394,7 @@ static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, co
     }
     if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, false, true); else VR_RELAY(DIV_UNIT, true, false, false); }
     VR_RELAY(DIV_UNIT, false, false, false);
+#undef VR_RELAY2
 #undef VR_RELAY
 }
 
