@@ -271,6 +271,10 @@ def main():
             try:
                 stream_gbps = r.measureStreamRead(5)
                 vol_bytes = int(dims[0]) * int(dims[1]) * int(dims[2]) * b
+                packed = r.pack12Bytes()
+                if packed:      # the launch gathered from the lossless 12-bit copy (1.5 B per voxel)
+                    result["config"]["resident_copy"] = f"12-bit packed copy of the uint16 volume ({packed} B) for the prefix gathers"
+                    vol_bytes = packed
                 result["roofline"]["measured_stream_read"] = round(stream_gbps, 1)
                 # reading the volume once + writing the frame at that rate: the floor of any layout
                 result["roofline"]["compulsory_floor_ms"] = round((vol_bytes + W * H * 16) / stream_gbps / 1e6, 4)

@@ -143,6 +143,8 @@ int vr_set_kernel_variant(vr_handle h, int variant);
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %
    fewer cache lines per frame; frames are bit-identical); 0: never.  Build-defined. */
 int vr_set_pack12(vr_handle h, int enable);
+/* bytes of the packed copy the last vr_render* gathered from (0: the launch used the volume as loaded) */
+int vr_get_pack12_bytes(vr_handle h, size_t *bytes);
 /* 1-D transfer function (N3): n knots of (iso in 0..255, r,g,b,a); n = 0 restores the
    reference grey ramp.  Built with the natural cubic spline of src/CubicSpline.cpp. */
 int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n);

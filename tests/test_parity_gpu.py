@@ -614,6 +614,7 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
                 block = r.getCameraBlock()
                 r.render()
                 frames[pack] = r.readPixels()
+                assert (r.pack12Bytes() > 0) == bool(pack), (dims, pack)     # 1.5 bytes per storage voxel, or not used
                 _, spp = r.countSamples(per_pixel=True)
                 assert r.last_kernel_name in FAST_KERNELS
         want, _, want_spp = oracle.render(vol, oracle.OracleParams(96, 80, cam=block, alpha_scale=0.05, min_val=0, max_val=4095), want_spp=True)
@@ -626,6 +627,7 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
         r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED); r.setVolume(vol); r.setWindow(0, 65535); r.setAlpha(0.3)
         r.render()
         got = r.readPixels()
+        assert r.pack12Bytes() == 0
     want, _ = oracle.render(vol, oracle.OracleParams(64, 64, alpha_scale=0.3, min_val=0, max_val=65535))
     assert_same(got, want, what="u16 volume with a voxel > 4095")
 

@@ -86,6 +86,7 @@ public:
     // best-of-`reps` streaming read of the resident volume; returns GB/s (1e9 bytes per second)
     double measureStreamRead(int reps);
     const char *lastKernelName() const { return last_kernel_; }
+    size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     bool hasDevice() const { return device_ >= 0; }
 
     int filter = 0, accum = 0, layout = 0, skip_empty = 0;
@@ -126,6 +127,7 @@ private:
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
     void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)
     size_t vol12_bytes_ = 0;
+    size_t last_packed12_bytes_ = 0;         // packed copy used by the last launch (0 = none)
     void refreshPacked12(const FrameParams &P, LaunchConfig &L);
     size_t skip_grid_cells_ = 0;
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);

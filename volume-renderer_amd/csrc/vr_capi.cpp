@@ -321,6 +321,14 @@ int vr_set_pack12(vr_handle h, int enable)
     return guarded(h, [&](vr::RendererCore &c) { c.pack12 = enable != 0; });
 }
 
+int vr_get_pack12_bytes(vr_handle h, size_t *bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        if (!bytes) throw std::invalid_argument("vr_get_pack12_bytes: null result");
+        *bytes = c.lastPacked12Bytes();
+    });
+}
+
 int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n)
 {
     return guarded(h, [&](vr::RendererCore &c) { c.setTransferFunction(iso, rgba4, n); });
