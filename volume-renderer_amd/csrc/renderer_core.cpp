@@ -607,10 +607,8 @@ void RendererCore::launch(uint32_t *spp)
     refreshSkipGrid(P, L);
     refreshTileSchedule(P, L);
     refreshPacked12(P, L);
-    // the headline shape is the one that gathers from the packed copy (vr_kernels.hip: dispatch_fast3 / dispatch_relay)
-    const bool headline = !L.mip && P.tf_len <= 1 && P.view_top != 1 && P.view_bottom != 1 && !(P.skip_empty != 0 && L.skip_grid) &&
-                          P.nx + P.ny + P.nz <= 3072;
-    last_packed12_bytes_ = (L.packed12 && headline) ? (size_t)L.packed12_bytes : 0;
+    // the specialised kernels gather from the packed copy when their address tables fit (vr_kernels.hip: dispatch_fast3)
+    last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
 }
 

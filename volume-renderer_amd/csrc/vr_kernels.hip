@@ -1411,16 +1411,16 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     // the skipping-free build exists for the headline shape only (MODE 0, default view)
     constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
-    // LDS address tables: headline shape only (compile time), 32-bit offsets, nx + ny + nz entries fit;
-    // the 12-bit packed copy (host: refreshPacked12) rides on them
-    const bool atab = HEADLINE && !BIG && noskip && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
-    constexpr bool CAN_ATAB = HEADLINE && !BIG, CAN_PK12 = CAN_ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1;
+    // LDS address tables whenever offsets are 32-bit and nx + ny + nz entries fit; the 12-bit
+    // packed copy (host: refreshPacked12) rides on them
+    constexpr bool CAN_ATAB = !BIG, CAN_PK12 = CAN_ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1;
+    const bool atab = CAN_ATAB && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
     const bool pk12 = atab && CAN_PK12 && L.packed12 != nullptr;
-#define VR_LAUNCH(TC, LT, P2, NC)                                                                                         \
-    (pk12 ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, CAN_ATAB, CAN_PK12>(P, L, vol, tf, fb, spp, rows, st) \
-     : atab ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, CAN_ATAB, false>(P, L, vol, tf, fb, spp, rows, st) \
-     : noskip ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, !HEADLINE, 8, false, false>(P, L, vol, tf, fb, spp, rows, st) \
-            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, true, 8, false, false>(P, L, vol, tf, fb, spp, rows, st))
+#define VR_LAUNCH2(TC, LT, P2, NC, SK)                                                                                    \
+    (pk12 ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, SK, 8, CAN_ATAB, CAN_PK12>(P, L, vol, tf, fb, spp, rows, st) \
+     : atab ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, SK, 8, CAN_ATAB, false>(P, L, vol, tf, fb, spp, rows, st)  \
+            : launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, SK, 8, false, false>(P, L, vol, tf, fb, spp, rows, st))
+#define VR_LAUNCH(TC, LT, P2, NC) (noskip ? VR_LAUNCH2(TC, LT, P2, NC, !HEADLINE) : VR_LAUNCH2(TC, LT, P2, NC, true))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
         if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
@@ -1435,6 +1435,7 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     if (MODE != 2) return VR_LAUNCH(DIV_UNIT, false, false, false);
     return hipErrorInvalidValue;
 #undef VR_LAUNCH
+#undef VR_LAUNCH2
 }
 
 template <typename VoxelT, int LAYOUT, int VIEW, bool BIG>
