@@ -25,6 +25,16 @@
 #include "tile_schedule.h"
 #include "vr_kernels.h"
 
+// Translation units: the ray-march kernels of one (voxel type, layout) pair are ~150 template
+// instances each, so the Makefile compiles this file five times in parallel:
+//   VR_TU = 0..3  ray-march kernels of (u8|u16) x (linear|bricked) + their dispatch
+//   VR_TU = -1    helper kernels, launchers and the top-level launch_raymarch
+//   VR_TU = -2    (default) everything in one translation unit
+#ifndef VR_TU
+#define VR_TU -2
+#endif
+#define VR_TU_MAIN (VR_TU < 0)
+
 namespace vr {
 
 // ------------------------------------------------------------------ GLSL built-ins
@@ -51,6 +61,7 @@ __device__ __forceinline__ float div_mode(float a, float b, float r)
 // Exhaustive proof for one divisor: for every significand a in [1,2) (sign and
 // exponent do not change the rounding pattern in the normal range) the Markstein
 // quotient equals IEEE division.  bad != 0 afterwards means "use DIV_EXACT".
+#if VR_TU_MAIN
 __global__ void certify_div_kernel(float b, float r, unsigned *bad)
 {
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;   // 2^23 threads
@@ -62,6 +73,7 @@ __global__ void certify_div_kernel(float b, float r, unsigned *bad)
     float a2 = a * 0.00390625f;
     if (__float_as_uint(div_cert(a2, b, r)) != __float_as_uint(a2 / b)) atomicOr(bad, 1u);
 }
+#endif  // VR_TU_MAIN
 
 // ------------------------------------------------------------------ tile mapping
 // Blocks are numbered so that the hardware's round-robin block->XCD placement
@@ -468,7 +480,7 @@ constexpr unsigned FAST_THREADS = 512, FAST_TILE_W = kFastTileW, FAST_TILE_H = k
 
 struct FastGrid { unsigned tiles_x, tiles_y, chunks_per_row, blocks; };
 
-static inline FastGrid fast_grid(int img_w, int rows)
+[[maybe_unused]] static inline FastGrid fast_grid(int img_w, int rows)
 {
     FastGrid g;
     g.tiles_x = (unsigned)((img_w + (int)FAST_TILE_W - 1) / (int)FAST_TILE_W);
@@ -1158,6 +1170,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     if (spp) spp[pix] = hit ? (uint32_t)i : 0u;
 }
 
+#if VR_TU_MAIN
 // ------------------------------------------------------------------ helper kernels
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -1317,7 +1330,9 @@ __global__ __launch_bounds__(256) void dilate_kernel(const uint16_t *__restrict_
 }
 
 // ------------------------------------------------------------------ launchers
-static inline unsigned padded_blocks(unsigned tiles_x, unsigned tiles_y)
+#endif  // VR_TU_MAIN
+
+[[maybe_unused]] static inline unsigned padded_blocks(unsigned tiles_x, unsigned tiles_y)
 {
     // every XCD gets ceil(tiles_y/8) tile rows' worth of slots; extras are padding
     const unsigned rows0 = (tiles_y + 7u) / 8u;
@@ -1479,6 +1494,30 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
 }
 #endif
 
+// ray-march launch of one (voxel type, layout) pair: the specialised kernels when `fast`, else
+// the generic one
+template <typename T, int LAY>
+static hipError_t raymarch_tu(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                              uint32_t *spp, int rows, bool fast, hipStream_t st)
+{
+    if (fast) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);
+    const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
+    return spp ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)
+               : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);
+}
+
+#define VR_TU_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, int rows, bool fast, hipStream_t st
+#if VR_TU == 0
+hipError_t launch_raymarch_tu0(VR_TU_ARGS) { return raymarch_tu<uint8_t, 0>(P, L, vol, tf, fb, spp, rows, fast, st); }
+#elif VR_TU == 1
+hipError_t launch_raymarch_tu1(VR_TU_ARGS) { return raymarch_tu<uint8_t, 1>(P, L, vol, tf, fb, spp, rows, fast, st); }
+#elif VR_TU == 2
+hipError_t launch_raymarch_tu2(VR_TU_ARGS) { return raymarch_tu<uint16_t, 0>(P, L, vol, tf, fb, spp, rows, fast, st); }
+#elif VR_TU == 3
+hipError_t launch_raymarch_tu3(VR_TU_ARGS) { return raymarch_tu<uint16_t, 1>(P, L, vol, tf, fb, spp, rows, fast, st); }
+#endif
+
+#if VR_TU_MAIN
 // The specialised kernel covers NEAREST + iterative accumulation with a non-degenerate
 // window whose divisions were certified and alpha_scale in [0,1]: grey-ramp composite,
 // grey-ramp MIP, and composite through a transfer-function table that fits LDS.
@@ -1505,27 +1544,36 @@ int launch_local_rows(const FrameParams &P)
     return rows;
 }
 
+#if VR_TU == -1
+hipError_t launch_raymarch_tu0(VR_TU_ARGS);
+hipError_t launch_raymarch_tu1(VR_TU_ARGS);
+hipError_t launch_raymarch_tu2(VR_TU_ARGS);
+hipError_t launch_raymarch_tu3(VR_TU_ARGS);
+#endif
+
 hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                            float4 *fb, uint32_t *spp, hipStream_t st, const char **kernel_name)
 {
     const int rows = launch_local_rows(P);   // local image rows covered by this launch
     if (rows <= 0 || P.img_w <= 0) return hipSuccess;
-    const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
-    const bool count = spp != nullptr;
     const bool fast = fast_path_eligible(P, L);
     if (kernel_name) *kernel_name = !fast ? "raymarch_generic_kernel" : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel");
-#define VR_GO(T, LAY)                                                                                        \
-    do {                                                                                                      \
-        if (fast) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);                                 \
-        return count ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)             \
-                     : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);           \
-    } while (0)
-    if (L.bytes_per_voxel == 1) {
-        if (L.layout == 0) VR_GO(uint8_t, 0); else VR_GO(uint8_t, 1);
-    } else {
-        if (L.layout == 0) VR_GO(uint16_t, 0); else VR_GO(uint16_t, 1);
+    const int tu = (L.bytes_per_voxel == 1 ? 0 : 2) + (L.layout == 0 ? 0 : 1);
+#if VR_TU == -1
+    switch (tu) {
+    case 0: return launch_raymarch_tu0(P, L, vol, tf, fb, spp, rows, fast, st);
+    case 1: return launch_raymarch_tu1(P, L, vol, tf, fb, spp, rows, fast, st);
+    case 2: return launch_raymarch_tu2(P, L, vol, tf, fb, spp, rows, fast, st);
+    default: return launch_raymarch_tu3(P, L, vol, tf, fb, spp, rows, fast, st);
     }
-#undef VR_GO
+#else
+    switch (tu) {
+    case 0: return raymarch_tu<uint8_t, 0>(P, L, vol, tf, fb, spp, rows, fast, st);
+    case 1: return raymarch_tu<uint8_t, 1>(P, L, vol, tf, fb, spp, rows, fast, st);
+    case 2: return raymarch_tu<uint16_t, 0>(P, L, vol, tf, fb, spp, rows, fast, st);
+    default: return raymarch_tu<uint16_t, 1>(P, L, vol, tf, fb, spp, rows, fast, st);
+    }
+#endif
 }
 
 hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
@@ -1630,5 +1678,7 @@ hipError_t launch_stats(const void *vol, int bytes_per_voxel, uint32_t nx, uint3
                            nz, layout, bnx, bny, pass, scale255, d_minmax, d_hist);
     return hipGetLastError();
 }
+
+#endif  // VR_TU_MAIN
 
 }  // namespace vr
