@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--stripe-rows", type=int, default=16)
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
     ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay)")
+    ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
     ap.add_argument("--shard", type=int, nargs=2, default=None, metavar=("WORLD", "RANK"),
                     help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,6 +116,7 @@ def main():
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
     r.setSkipEmpty(args.skip_empty)
     r.setKernelVariant(args.kernel_variant)
+    r.setPack12(not args.no_pack12)
     r.setAlpha(args.alpha)
     r.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
     if args.pose == "offaxis":
