@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--layout", choices=("linear", "bricked"), default=os.environ.get("VR_BENCH_LAYOUT", "bricked"))
     ap.add_argument("--partition", choices=("stripes", "contiguous"), default="stripes")
     ap.add_argument("--stripe-rows", type=int, default=16)
+    ap.add_argument("--gather-format", choices=("auto", "rgba", "ga"), default="auto",
+                    help="N > 1: what the all_gather moves -- RGBA32F, or (grey, alpha) float2 in the grey modes "
+                         "(r == g == b there; expanded to RGBA after the gather); auto = ga when the mode is grey")
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
     ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay)")
     ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
@@ -137,8 +140,14 @@ def main():
     # second stream while the kernel of frame i+1 renders into the other slot.
     nslots = 2 if world > 1 else 1
     comm_stream = torch.cuda.Stream(dev) if world > 1 else None
-    locals_ = [torch.zeros((plan.local_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)]
-    gathered = [torch.empty((world * plan.local_rows, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
+    # N > 1 in a grey mode: shards are rendered and gathered as (grey, alpha) -- half the bytes over xGMI
+    grey_alpha = world > 1 and not args.tf and args.gather_format in ("auto", "ga")
+    if args.gather_format == "ga" and args.tf:
+        raise SystemExit("--gather-format ga needs a grey mode (no --tf)")
+    C4 = 2 if grey_alpha else 4
+    r.setFramebufferFormat(R.FB_GREYALPHA32F if grey_alpha else R.FB_RGBA32F)
+    locals_ = [torch.zeros((plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)]
+    gathered = [torch.empty((world * plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
     ev_rendered = [torch.cuda.Event() for _ in range(nslots)]
     ev_gathered = [torch.cuda.Event() for _ in range(nslots)]
     local = locals_[0]
@@ -254,7 +263,7 @@ def main():
                 "samples_per_frame": total_samples,
                 "partition": "single GPU" if world == 1 else f"{args.partition} rows x{world}"
                              + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
-                             + " + RCCL all_gather",
+                             + (" + RCCL all_gather of (grey, alpha) shards" if grey_alpha else " + RCCL all_gather"),
                 "kernel": r.last_kernel_name,
             },
             "roofline": {

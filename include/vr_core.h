@@ -158,6 +158,13 @@ int vr_set_row_stripes(vr_handle h, int stripe_rows, int index, int count);
    offset r*fb_w (contiguous shard: r = row - row_begin; stripes: stripe-major).  Only
    meaningful with an external target; vr_local_rows() gives its height in rows. */
 int vr_set_framebuffer_compact(vr_handle h, int compact);
+/* format of an EXTERNAL target: VR_FB_RGBA32F (default, 4 floats per pixel) or
+   VR_FB_GREYALPHA32F (2 floats per pixel: the grey value and alpha; in the reference's grey
+   modes r == g == b bit for bit, so this is the same frame in half the bytes -- what a
+   multi-GPU gather moves).  Rendering with a transfer function into it fails (VR_E_INVALID). */
+#define VR_FB_RGBA32F 0
+#define VR_FB_GREYALPHA32F 1
+int vr_set_framebuffer_format(vr_handle h, int format);
 int vr_local_rows(vr_handle h);
 /* launch on a caller-owned HIP stream (hipStream_t as void*); NULL = own stream */
 int vr_set_stream(vr_handle h, void *hip_stream);

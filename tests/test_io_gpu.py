@@ -118,6 +118,34 @@ def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
     assert jpg.shape == (52, 77, 3) and np.abs(jpg - want.astype(np.int32)).max() <= 3
 
 
+def test_grey_alpha_target_is_the_same_frame_in_half_the_bytes(vra, oracle):
+    """vr_set_framebuffer_format(VR_FB_GREYALPHA32F): (grey, alpha) per pixel into an external
+    target, composite and MIP, fast and generic kernels; a transfer function is refused"""
+    import torch
+
+    R = vra.renderer
+    sharding = __import__("importlib").import_module("volume-renderer_amd.sharding")
+    vol = oracle.gen_noise_ball((48, 40, 44), 2, 9)
+    W, H = 100, 70
+    with make(vra, (W, H)) as r:
+        r.setQuirks(0); r.setVolume(vol); r.setWindow(0, 4095); r.setAlpha(0.05)
+        for mip, variant in ((False, 0), (True, 0), (False, 1)):
+            r.setMIP(mip); r.setKernelVariant(variant)
+            r.setFramebufferExternal(0); r.setFramebufferFormat(R.FB_RGBA32F)
+            r.render(); want = r.readPixels().copy()
+            ga = torch.full((H, W, 2), -1.0, dtype=torch.float32, device="cuda:0")
+            r.setFramebufferExternal(ga.data_ptr()); r.setFramebufferFormat(R.FB_GREYALPHA32F)
+            r.render(); torch.cuda.synchronize()
+            got = sharding.expand_grey_alpha(ga).cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (mip, variant)
+        r.setMIP(False); r.setKernelVariant(0)
+        r.setTransferFunction([0, 255], [[0, 0, 0, 0], [1, 0.5, 0.2, 1]])
+        with pytest.raises(Exception):
+            r.render()
+        r.setFramebufferExternal(0); r.setFramebufferFormat(R.FB_RGBA32F)
+        r.render()                                   # the RGBA target takes any mode
+
+
 def test_external_target_stream_and_compact_shard(vra, oracle):
     import torch
 

@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir):
+def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir, grey_alpha=False):
     import torch
     import torch.distributed as dist
 
@@ -45,19 +45,22 @@ def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir):
         p.row_begin, p.row_end = int(g), int(g) + 1
         oracle.render(vol, p, out=full)
         local[lr] = full[g]
+    if grey_alpha:      # what vr_set_framebuffer_format(VR_FB_GREYALPHA32F) makes the kernel store: (grey, alpha)
+        local = np.ascontiguousarray(local[..., [0, 3]])
     frame = sharding.gather_frame(torch.from_numpy(local), plan)
     np.save(os.path.join(out_dir, f"frame_{mode}_{rank}.npy"), frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,stripe_rows", [("contiguous", 16), ("stripes", 8), ("stripes", 16)])
-def test_two_rank_gather_reassembles_the_frame(mode, stripe_rows, tmp_path, oracle):
+@pytest.mark.parametrize("mode,stripe_rows,grey_alpha", [("contiguous", 16, False), ("stripes", 8, False), ("stripes", 16, False),
+                                                         ("stripes", 16, True), ("contiguous", 16, True)])
+def test_two_rank_gather_reassembles_the_frame(mode, stripe_rows, grey_alpha, tmp_path, oracle):
     import torch.multiprocessing as mp
 
     W, H, world = 40, 53, 2          # ragged: 53 rows
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, mode, stripe_rows, W, H, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, mode, stripe_rows, W, H, str(tmp_path), grey_alpha), nprocs=world, join=True)
     vol = oracle.gen_noise_ball((24, 20, 28), 1, 77)
     want, _ = oracle.render(vol, oracle.OracleParams(W, H, alpha_scale=0.05))
     for rank in range(world):

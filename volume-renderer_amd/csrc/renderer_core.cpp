@@ -522,6 +522,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     P.stripe_index = stripe_index_;
     P.stripe_count = stripe_count_;
     P.fb_compact = fb_compact_ ? 1 : 0;
+    P.fb_format = (fb_format_ == 1 && ext_fb_) ? 1 : 0;
     const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
     P.nx = nx; P.ny = ny; P.nz = nz;
     P.fdim[0] = (float)nx; P.fdim[1] = (float)ny; P.fdim[2] = (float)nz;
@@ -594,6 +595,12 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.divmode_win = (P.fden > 0.0f && certifyDivisor(P.fden)) ? DIV_CERT : DIV_EXACT;
 }
 
+void RendererCore::setFramebufferFormat(int fmt)
+{
+    if (fmt != 0 && fmt != 1) throw std::invalid_argument("setFramebufferFormat: unknown format");
+    fb_format_ = fmt;
+}
+
 void RendererCore::launch(uint32_t *spp)
 {
     requireDevice("render");
@@ -601,6 +608,8 @@ void RendererCore::launch(uint32_t *spp)
     if (!d_vol_) throw std::runtime_error("render: no dataset loaded");
     float4 *fb = ext_fb_ ? reinterpret_cast<float4 *>(ext_fb_) : d_fb_;
     if (!fb) throw std::runtime_error("render: setup() has not allocated the framebuffer");
+    if (fb_format_ == 1 && ext_fb_ && !tf_lut_.empty())
+        throw std::invalid_argument("render: the (grey, alpha) target format needs a grey mode (no transfer function)");
     FrameParams P;
     LaunchConfig L;
     buildFrame(P, L);

@@ -81,6 +81,7 @@ public:
     void setRowRange(int b, int e) { row_begin_ = b; row_end_ = e; }
     void setRowStripes(int rows, int index, int count);
     void setFramebufferCompact(bool on) { fb_compact_ = on; }
+    void setFramebufferFormat(int fmt);      // 0 RGBA32F, 1 (grey, alpha) float2 -- external targets, grey modes
     int localRows() const;   // rows this handle renders (stripe padding included)
     void computeHistogram(float out[256]);
     // best-of-`reps` streaming read of the resident volume; returns GB/s (1e9 bytes per second)
@@ -123,6 +124,7 @@ private:
     int row_begin_ = 0, row_end_ = -1;
     int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;
     bool fb_compact_ = false;
+    int fb_format_ = 0;
     std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
     void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)

@@ -355,6 +355,11 @@ int vr_set_row_stripes(vr_handle h, int stripe_rows, int index, int count)
     return guarded(h, [&](vr::RendererCore &c) { c.setRowStripes(stripe_rows, index, count); });
 }
 
+int vr_set_framebuffer_format(vr_handle h, int format)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.setFramebufferFormat(format); });
+}
+
 int vr_set_framebuffer_compact(vr_handle h, int compact)
 {
     return guarded(h, [&](vr::RendererCore &c) { c.setFramebufferCompact(compact != 0); });

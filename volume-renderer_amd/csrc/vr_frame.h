@@ -28,6 +28,7 @@ struct FrameParams {
     int32_t col_lim, row_lim;      // Q1 limits (== img_w/img_h when the quirk is off)
     int32_t stripe_rows, stripe_index, stripe_count;  // cyclic row stripes (count 1 = off)
     int32_t fb_compact;            // 1: target holds only this shard's rows (local row index)
+    int32_t fb_format;             // 0: RGBA32F; 1: (grey, alpha) float2 per pixel (grey modes only: r == g == b)
     int32_t nx, ny, nz;            // textureSize(vol_tex3D)
     float fdim[3];                 // float(textureSize)
     float half[3];                 // half_len

@@ -96,6 +96,14 @@ __device__ __forceinline__ void tile_of_block(unsigned b, unsigned tiles_x, unsi
 }
 
 // ------------------------------------------------------------------ ray setup
+// final store of a pixel: RGBA32F, or (grey, alpha) float2 when the caller asked for the
+// half-size target of the grey modes (vr_set_framebuffer_format; r == g == b there)
+__device__ __forceinline__ void store_pixel(const FrameParams &P, float4 *__restrict__ fb, size_t pix, float r, float g, float b, float a)
+{
+    if (P.fb_format == 1) reinterpret_cast<float2 *>(fb)[pix] = make_float2(r, a);
+    else fb[pix] = make_float4(r, g, b, a);
+}
+
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 
 // VolumeRenderer.cs:194-216
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
         }
     }
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    fb[pix] = make_float4(d0, d1, d2, d3);
+    store_pixel(P, fb, pix, d0, d1, d2, d3);
     if (COUNT) spp[pix] = fetches;
 }
 
@@ -864,7 +872,9 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    fb[pix] = MODE == 2 ? make_float4(drgb, dg, db, da) : (MODE == 1 ? make_float4(da, da, da, da) : make_float4(drgb, drgb, drgb, da));
+    if (MODE == 2) store_pixel(P, fb, pix, drgb, dg, db, da);
+    else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
+    else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
 #ifdef VR_EXP_TRACE
     if (spp && (threadIdx.x & 63u) == 0) {
         const unsigned w = blockIdx.x * 8u + (threadIdx.x >> 6);
@@ -1166,7 +1176,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    fb[pix] = make_float4(drgb, drgb, drgb, da);
+    store_pixel(P, fb, pix, drgb, drgb, drgb, da);
     if (spp) spp[pix] = hit ? (uint32_t)i : 0u;
 }
 

@@ -26,6 +26,7 @@ VR_OK, VR_E_INVALID, VR_E_NO_DEVICE, VR_E_HIP, VR_E_IO, VR_E_NOMEM = range(6)
 FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 ACCUM_ITERATIVE, ACCUM_CLOSED_FORM = 0, 1
 LAYOUT_LINEAR, LAYOUT_BRICKED = 0, 1
+FB_RGBA32F, FB_GREYALPHA32F = 0, 1     # vr_set_framebuffer_format
 SYNTH_SPHERE_U8, SYNTH_NOISE_BALL = 0, 1
 QUIRK_TRUNC_GRID, QUIRK_U16_OFFSET = 1, 2
 QUIRK_DEFAULT = QUIRK_U16_OFFSET
@@ -121,6 +122,7 @@ def load_library() -> C.CDLL:
         "vr_set_row_range": (i32, [h, i32, i32]),
         "vr_set_row_stripes": (i32, [h, i32, i32, i32]),
         "vr_set_framebuffer_compact": (i32, [h, i32]),
+        "vr_set_framebuffer_format": (i32, [h, i32]),
         "vr_local_rows": (i32, [h]),
         "vr_set_stream": (i32, [h, C.c_void_p]),
         "vr_set_framebuffer_external": (i32, [h, C.c_void_p]),
@@ -389,6 +391,10 @@ class RendererCore:
 
     def setFramebufferCompact(self, on):
         self._check(self._lib.vr_set_framebuffer_compact(self._h, int(bool(on))))
+
+    def setFramebufferFormat(self, fmt):
+        """FB_RGBA32F or FB_GREYALPHA32F (external targets; grey modes only)"""
+        self._check(self._lib.vr_set_framebuffer_format(self._h, int(fmt)))
 
     def localRows(self) -> int:
         return int(self._lib.vr_local_rows(self._h))

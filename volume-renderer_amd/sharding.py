@@ -81,17 +81,30 @@ def gather_index(plan: RowPlan):
     return idx
 
 
+def expand_grey_alpha(ga):
+    """[..., 2] (grey, alpha) -> [..., 4] (grey, grey, grey, alpha): the RGBA32F frame of the
+    reference's grey modes, in which r == g == b bit for bit"""
+    import torch
+
+    sel = torch.tensor([0, 0, 0, 1], device=ga.device)
+    return ga.index_select(-1, sel)
+
+
 def gather_frame(local, plan: RowPlan, out=None, index=None):
     """all_gather the compact shards and return the assembled [H, W, 4] frame.
 
-    local: torch tensor [local_rows, W, 4] on this rank's device.  One collective
-    (RCCL all_gather over xGMI on GPUs) + one index_select to undo the interleave.
+    local: torch tensor [local_rows, W, C] on this rank's device, C = 4 (RGBA32F) or C = 2
+    ((grey, alpha) targets, vr_set_framebuffer_format: half the bytes on the wire; expanded to
+    RGBA after the gather).  One collective (RCCL all_gather over xGMI on GPUs) + one
+    index_select to undo the interleave.
     """
     import torch
     import torch.distributed as dist
 
+    grey_alpha = local.shape[-1] == 2
     if plan.world == 1:
-        return local[: plan.img_h]
+        frame = local[: plan.img_h]
+        return expand_grey_alpha(frame) if grey_alpha else frame
     if out is None:
         out = torch.empty((plan.world * plan.local_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if local.is_cuda and dist.get_backend() == "gloo":
@@ -102,7 +115,9 @@ def gather_frame(local, plan: RowPlan, out=None, index=None):
     else:
         dist.all_gather_into_tensor(out, local)
     if plan.mode == "contiguous":
-        return out[: plan.img_h]
-    if index is None:
-        index = torch.as_tensor(gather_index(plan), device=local.device)
-    return out.index_select(0, index)
+        frame = out[: plan.img_h]
+    else:
+        if index is None:
+            index = torch.as_tensor(gather_index(plan), device=local.device)
+        frame = out.index_select(0, index)
+    return expand_grey_alpha(frame) if grey_alpha else frame
