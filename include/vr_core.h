@@ -68,6 +68,11 @@ int vr_take_message(vr_handle h, char *title, size_t title_cap, char *msg, size_
         (src/Camera.cpp:30-151; bound at RendererGUI.cpp:42-46, :363) ---------- */
 int vr_camera_orient(vr_handle h, float zoom, float zenith, float azimuth);
 int vr_camera_reset(vr_handle h);
+/* Camera::setViewMatrix(eye, side, up, look_at) (include/Camera.h:18, src/Camera.cpp:46-57):
+   four xyzw vectors; the members are normalised, the matrix is built from the arguments as
+   given (columns side, up, -look_at, eye), exactly like the reference */
+int vr_camera_set_view_matrix(vr_handle h, const float eye4[4], const float side4[4], const float up4[4],
+                              const float look_at4[4]);
 int vr_camera_set_block(vr_handle h, const float block21[21]);
 int vr_camera_get_block(vr_handle h, float block21[21]);
 

@@ -185,3 +185,15 @@ def test_image_writers_host_only(vra, tmp_path):
     assert vra.write_image_rgb8(tmp_path / "g.jpg", ".jpg", grey)
     assert np.abs(np.asarray(Image.open(tmp_path / "g.jpg").convert("RGB")).astype(int) - 137).max() <= 1
     assert not vra.write_image_rgb8(tmp_path / "a.gif", ".gif", img)
+
+
+def test_camera_set_view_matrix_mirrors_the_reference(vra):
+    """Camera::setViewMatrix (src/Camera.cpp:46-57): columns side, up, -look_at, eye as GIVEN
+    (not normalised), eye appended, view_plane_dist kept"""
+    with vra.RendererCore(-1) as r:
+        d = float(r.getCameraBlock()[20])
+        eye, side, up, look = (1.0, 2.0, 3.0, 1.0), (2.0, 0.0, 0.0, 0.0), (0.0, 0.5, 0.0, 0.0), (0.0, 0.0, -4.0, 0.0)
+        r.setViewMatrix(eye, side, up, look)
+        b = r.getCameraBlock()
+    want = np.array(list(side) + list(up) + [0.0, 0.0, 4.0, -0.0] + list(eye) + list(eye) + [d], dtype=np.float32)
+    assert np.array_equal(b, want)

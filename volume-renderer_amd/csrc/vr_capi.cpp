@@ -115,6 +115,17 @@ int vr_camera_reset(vr_handle h)
     return guarded(h, [&](vr::RendererCore &c) { c.main_cam.resetCamera(); c.main_cam.is_changed = true; });
 }
 
+int vr_camera_set_view_matrix(vr_handle h, const float eye4[4], const float side4[4], const float up4[4],
+                              const float look_at4[4])
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        if (!eye4 || !side4 || !up4 || !look_at4) throw std::invalid_argument("vr_camera_set_view_matrix: null vector");
+        auto v = [](const float *p) { return vr::Vec4{p[0], p[1], p[2], p[3]}; };
+        c.main_cam.setViewMatrix(v(eye4), v(side4), v(up4), v(look_at4));
+        c.main_cam.is_changed = true;
+    });
+}
+
 int vr_camera_set_block(vr_handle h, const float block21[21])
 {
     return guarded(h, [&](vr::RendererCore &c) {

@@ -88,6 +88,7 @@ def load_library() -> C.CDLL:
         "vr_camera_orient": (i32, [h, f32, f32, f32]),
         "vr_camera_reset": (i32, [h]),
         "vr_camera_set_block": (i32, [h, C.POINTER(f32)]),
+        "vr_camera_set_view_matrix": (i32, [h, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]),
         "vr_camera_get_block": (i32, [h, C.POINTER(f32)]),
         "vr_load_shader": (i32, [h, C.c_char_p, i32]),
         "vr_workgroups": (i32, [h, C.POINTER(i32), C.POINTER(i32)]),
@@ -234,6 +235,12 @@ class RendererCore:
 
     def resetCamera(self):
         self._check(self._lib.vr_camera_reset(self._h))
+
+    def setViewMatrix(self, eye, side, up, look_at):
+        """Camera::setViewMatrix: four xyzw vectors"""
+        v = [np.ascontiguousarray(x, dtype=np.float32) for x in (eye, side, up, look_at)]
+        assert all(x.size == 4 for x in v)
+        self._check(self._lib.vr_camera_set_view_matrix(self._h, *[_fp(x) for x in v]))
 
     def setCameraBlock(self, block21):
         b = np.ascontiguousarray(block21, dtype=np.float32)
