@@ -582,7 +582,9 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         L.big_offsets = small ? 0 : 1;
         L.vol_bytes32 = small ? (uint32_t)bytes : 0u;
         const int64_t width = (int64_t)u_.max_val - (int64_t)u_.min_val + 1;
-        L.use_lut = (width >= 2 && width <= (tf_lut_.empty() ? 4096 : 2048)) ? 1 : 0;
+        // LDS classification table: 4096 (c,a) entries, or with a transfer function one index byte per
+        // window value behind the 256-entry RGBA table (vr_kernels.hip: FAST_TF_WINDOW_MAX)
+        L.use_lut = (width >= 2 && width <= (tf_lut_.empty() ? 4096 : FAST_TF_WINDOW_MAX) && (tf_lut_.empty() || tf_lut_.size() / 4 <= 256)) ? 1 : 0;
         L.lut_noclamp = (exact_min_ >= u_.min_val && exact_max_ <= u_.max_val) ? 1 : 0;
         auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
         L.pow2_dims = (is_pow2(nx) && is_pow2(ny) && is_pow2(nz)) ? 1 : 0;

@@ -21,6 +21,10 @@ constexpr int BRICK_LX = VR_BRICK_LX, BRICK_LY = VR_BRICK_LY, BRICK_LZ = VR_BRIC
 constexpr int BRICK_X = 1 << BRICK_LX, BRICK_Y = 1 << BRICK_LY, BRICK_Z = 1 << BRICK_LZ;
 static_assert(BRICK_LX + BRICK_LY + BRICK_LZ == 6 && BRICK_LX >= 1, "bricks hold 64 voxels");
 
+// widest window (in voxel values) the specialised kernels classify through LDS with a transfer
+// function: one index byte per value behind the 256-entry RGBA table in a 32 KiB array
+constexpr int FAST_TF_WINDOW_MAX = 4096 * 8 - 256 * 16;
+
 struct FrameParams {
     float cam[21];                 // view_mat columns, eye, view_plane_dist
     int32_t img_w, img_h;          // imageSize(render_texture)

@@ -229,6 +229,10 @@ __device__ __forceinline__ void build_axis_tables(const FrameParams &P, uint32_t
 // for e in [0, max_val-min_val] in LDS with the shader's own operations (so entries are
 // bit-identical to the per-sample computation) and a sample then costs one ds_read_b64.
 constexpr int FAST_LUT_MAX = 4096;      // entries (x 8 B = 32 KiB of the CU's 160 KiB LDS)
+// MODE 2 (transfer function) is two-level: 256 premultiplied RGBA entries (4 KiB) + one index
+// byte per windowed voxel value in the remaining 28 KiB, so any window up to 28672 values fits
+constexpr int FAST_TF_ENTRIES = 256;
+static_assert(FAST_TF_WINDOW_MAX == FAST_LUT_MAX * 8 - FAST_TF_ENTRIES * 16, "vr_frame.h: FAST_TF_WINDOW_MAX");
 // Address tables (ATAB): the byte offset of voxel (i,j,k) is X[i] + Y[j] + Z[k] in both layouts,
 // so the ~10 integer VALU ops of VoxelAddr become three LDS look-ups and one add; integer ops
 // issue at ~1.6x the cost of fp32 ops on gfx950 and are 40 % of the inner loop's issue time.
@@ -544,7 +548,6 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
 {
     static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
     static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH == 8), "12-bit copy: u16 bricks through the address tables");
-    constexpr int LUT_STRIDE = MODE == 2 ? 4 : 2;          // floats per entry
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
     __shared__ uint32_t axis_tab[ATAB ? FAST_AXIS_TAB_MAX : 1];
     static_assert(!ATAB || !BIG, "address tables hold 32-bit byte offsets");
@@ -593,16 +596,21 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
                 const float v = div_cert(s - P.fmin, P.fden, P.rden);
                 if (MODE == 2) {
-                    // classification through the transfer function: index = round(v*(len-1)),
-                    // src.a *= alpha_scale, src.rgb *= src.a
+                    // classification through the transfer function: index = round(v*(len-1)) here,
+                    // src.a *= alpha_scale, src.rgb *= src.a in the 256-entry table below
                     int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
                     idx = clampi(idx, 0, P.tf_len - 1);
-                    const float4 t = tf[idx];
-                    const float a = t.w * P.alpha_scale;
-                    lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a; lut[4 * e + 3] = a;
+                    reinterpret_cast<uint8_t *>(lut)[FAST_TF_ENTRIES * 16 + e] = (uint8_t)idx;
                 } else {
                     const float a = v * P.alpha_scale;
                     lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
+                }
+            }
+            if (LUT && MODE == 2) {
+                for (int e = (int)threadIdx.x; e < P.tf_len; e += (int)FAST_THREADS) {
+                    const float4 t = tf[e];
+                    const float a = t.w * P.alpha_scale;
+                    lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a; lut[4 * e + 3] = a;
                 }
             }
             __syncthreads();
@@ -637,19 +645,21 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
             vj = (int)(tcy * P.fdim[1]);
             vk = (int)(tcz * P.fdim[2]);
         };
-        constexpr int LUT_SHIFT = MODE == 2 ? 4 : 3;
-        const int lut_bias = -(4 * LUT_STRIDE) * P.min_val;   // byte offset of entry 0 relative to texel*entry_bytes
+        constexpr int LUT_SHIFT = 3;
+        // byte offset of entry 0 relative to texel*entry_bytes (MODE 2: of index byte 0 relative to texel)
+        const int lut_bias = MODE == 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
         // window + classification of one texel -> premultiplied colour c (cg, cb only in MODE 2)
         // and opacity a of VolumeRenderer.cs:130-131
         auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
             if (LUT) {
                 int t = (int)texel;
                 if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);   // clamp(texel, min_val, max_val), min <= max
-                const char *entry = reinterpret_cast<const char *>(lut) + (uint32_t)((t << LUT_SHIFT) + lut_bias);
                 if (MODE == 2) {
-                    const float4 q = *reinterpret_cast<const float4 *>(entry);
+                    const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[(uint32_t)(t + lut_bias)];
+                    const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
                     c = q.x; cg = q.y; cb = q.z; a = q.w;
                 } else {
+                    const char *entry = reinterpret_cast<const char *>(lut) + (uint32_t)((t << LUT_SHIFT) + lut_bias);
                     const float2 ca = *reinterpret_cast<const float2 *>(entry);
                     c = ca.x; a = ca.y;
                 }
