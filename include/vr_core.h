@@ -137,7 +137,7 @@ int vr_get_window(vr_handle h, int *min_val, int *max_val);
 int vr_set_filter(vr_handle h, int filter);          /* VR_FILTER_*  (F4)            */
 int vr_set_accum(vr_handle h, int accum);            /* VR_ACCUM_*   (Q8)            */
 int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*                   */
-int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_*; re-lays the volume out */
+int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_* (default BRICKED); re-lays the volume out */
 int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
 /* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches
    of the headline shape with fewer than 256 active 32x16 tiles use the 4-wavefront relay kernel),

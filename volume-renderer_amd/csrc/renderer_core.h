@@ -90,7 +90,8 @@ public:
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     bool hasDevice() const { return device_ >= 0; }
 
-    int filter = 0, accum = 0, layout = 0, skip_empty = 0;
+    int filter = 0, accum = 0, skip_empty = 0;
+    int layout = 1;          // VR_LAYOUT_BRICKED: the faster HBM layout is the default (vr_set_layout)
     uint32_t quirks = 2u;   // VR_QUIRK_DEFAULT
     int force_generic = 0;
     int pack12 = 1;                          // 1: keep a 12-bit packed copy for the fast kernel when the data allow (vr_set_pack12)
