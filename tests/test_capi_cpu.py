@@ -197,3 +197,31 @@ def test_camera_set_view_matrix_mirrors_the_reference(vra):
         b = r.getCameraBlock()
     want = np.array(list(side) + list(up) + [0.0, 0.0, 4.0, -0.0] + list(eye) + list(eye) + [d], dtype=np.float32)
     assert np.array_equal(b, want)
+
+
+def test_file_parsers_survive_mutated_inputs_under_sanitizers(tmp_path):
+    """tools/fuzz/fuzz_volume_io.cpp: the PVM/DDS decoder and the .raw.inf parser (the code that
+    reads untrusted files) on a few thousand mutated fixtures, built with ASan + UBSan"""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fuzz_volume_io"
+    build = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-I", os.path.join(root, "volume-renderer_amd", "csrc"),
+                            os.path.join(root, "tools", "fuzz", "fuzz_volume_io.cpp"),
+                            os.path.join(root, "volume-renderer_amd", "csrc", "volume_io.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert build.returncode == 0, build.stderr
+    inf = tmp_path / "seed.inf"
+    inf.write_text("#dimensions\n64 64 32\n#voxel-spacing\n1.0 1.0 2.5\n")
+    gold = os.path.join(root, "tests", "golden")
+    seeds = [os.path.join(gold, f) for f in ("pvm1_u8_9x7x5_noise.pvm", "pvm2_u16_8x6x4_scaled.pvm", "pvm3_u8_10x10x3_desc.pvm",
+                                              "pvm1_u8_13x11x6_ramp.pvm")] + [str(inf)]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1")
+    run = subprocess.run([str(exe), "4000"] + seeds, capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
+    assert run.returncode == 0 and "no crash" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
