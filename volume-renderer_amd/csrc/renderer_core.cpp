@@ -183,6 +183,7 @@ void RendererCore::freeVolume()
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
     if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
+    vol12_failed_ = false;
 }
 
 void RendererCore::allocVolume(int nx, int ny, int nz, int bytes, int lay)
@@ -638,7 +639,13 @@ void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
     const size_t bytes = voxels / 2 * 3;
     if (bytes + 16 >= (1ull << 32)) return;
     if (!d_vol12_) {
-        check(hipMalloc(&d_vol12_, bytes + 16), "hipMalloc(packed volume)");
+        if (vol12_failed_) return;
+        if (hipMalloc(&d_vol12_, bytes + 16) != hipSuccess) {     // an optimisation only: render from the volume as loaded
+            (void)hipGetLastError();
+            d_vol12_ = nullptr;
+            vol12_failed_ = true;
+            return;
+        }
         hipError_t e = launch_pack12(d_vol_, d_vol12_, voxels, stream());
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         if (e != hipSuccess) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; }

@@ -130,6 +130,7 @@ private:
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
     void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)
     size_t vol12_bytes_ = 0;
+    bool vol12_failed_ = false;              // allocation of the packed copy failed for this volume: do not retry
     size_t last_packed12_bytes_ = 0;         // packed copy used by the last launch (0 = none)
     void refreshPacked12(const FrameParams &P, LaunchConfig &L);
     size_t skip_grid_cells_ = 0;
