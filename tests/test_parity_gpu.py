@@ -669,8 +669,14 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
             if rng.random() < 0.2:
                 W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
         tf_lut = None
+        quirks, pack = 0, 1
+        if extended:
+            quirks = int(rng.integers(0, 4)) if rng.random() < 0.25 else 0     # Q1 truncated grid, Q10 +1000 (u16)
+            pack = 0 if rng.random() < 0.25 else 1
+        win_off = 1000 if (quirks & 2) and dtype == np.uint16 else 0
         with make_renderer(vra, (W, H)) as r:
-            r.setQuirks(0)
+            r.setQuirks(quirks)
+            r.setPack12(pack)
             r.setLayout(trial % 2)
             r.setVolume(vol, spacing)
             r.setWindow(lo, hi)
@@ -702,12 +708,12 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 r.render()
                 got = r.readPixels()
                 _, spp = r.countSamples(per_pixel=True)
-                p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi,
+                p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo + win_off, max_val=hi + win_off,
                                         view_top=int(top), view_bottom=int(bottom), is_mip=int(mip), filter=int(tri),
-                                        accum=int(accum), tf_rgba=tf_lut)
+                                        accum=int(accum), tf_rgba=tf_lut, trunc_grid=quirks & 1)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
                 what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
-                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} stripes {rows} kernel {r.last_kernel_name}")
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
                 if rows:                                       # only this shard's rows are rendered
                     mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
                     assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)
