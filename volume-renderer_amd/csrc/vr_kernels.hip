@@ -484,10 +484,11 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
 }
 
 // Workgroup = 512 threads = 8 wavefronts = a 32x16-pixel tile (4x2 wave tiles of 8x8).
-// Blocks are handed to XCDs in chunks of FAST_CHUNK horizontally adjacent tiles; with an
-// odd number of chunks per tile row the owner (chunk index mod 8) rotates from row to row,
-// so every XCD gets an equal share of every image region (the hit pixels are a centred
-// blob) while x-neighbours, which share cache lines, stay on one XCD's L2.
+// Normally the host's longest-first tile table (tile_schedule.cpp) maps blocks to tiles.  The
+// arithmetic order below is the table-less fallback (RendererCore::tile_order = 0): blocks go
+// to XCDs in chunks of FAST_CHUNK horizontally adjacent tiles, and with an odd number of chunks
+// per tile row the owner (chunk index mod 8) rotates from row to row, so every XCD gets an
+// equal share of every image region.
 constexpr unsigned FAST_THREADS = 512, FAST_TILE_W = kFastTileW, FAST_TILE_H = kFastTileH, FAST_CHUNK = kFastChunk;
 
 struct FastGrid { unsigned tiles_x, tiles_y, chunks_per_row, blocks; };
@@ -1388,8 +1389,8 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
 }
 
 // the relay kernel serves the headline shape (grey composite, default view, 32-bit offsets,
-// no skipping): it beats the lockstep fast kernel at every launch size measured (cfg3 frame
-// 0.59 vs 0.63 ms, 1/8 shard 0.095 vs 0.18 ms); L.sparse_shard is its on/off switch
+// no skipping); L.sparse_shard (host: fewer than 256 active tiles, or vr_set_kernel_variant)
+// is its on/off switch
 static bool relay_selected(const FrameParams &P, const LaunchConfig &L)
 {
     return L.sparse_shard && L.tile_table && !L.mip && P.tf_len <= 1 && !L.big_offsets && P.view_top != 1 &&
