@@ -428,23 +428,23 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
                     const uint32_t x0 = term_x(i0), x1 = term_x(i1), y0 = term_y(j0), y1 = term_y(j1);
                     const uint32_t z0 = term_z(k0), z1 = term_z(k1);
                     // the two x-neighbours of a tap pair are adjacent in memory unless i0 is the last
-                    // voxel of its brick row (or of the volume): one load of 2 voxels instead of 2
+                    // voxel of its brick row (or of the volume): every lane fetches its x0 tap together
+                    // with the next storage element in one load (bounds-checked: the last element of the
+                    // buffer reads 0 there), and only the lanes whose x1 lies elsewhere fetch it again
                     const bool pair = i1 == i0 + 1 && (LAYOUT == 0 || ((uint32_t)i0 & (BRICK_X - 1u)) != BRICK_X - 1u);
-                    if (pair) {
-                        auto tap2 = [&](uint32_t off, float &lo, float &hi) {
-                            if (sizeof(VoxelT) == 1) {
-                                const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
-                                lo = (float)(v & 0xffu); hi = (float)(v >> 8);
-                            } else {
-                                const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off << 1), 0, 0);
-                                lo = (float)(v & 0xffffu); hi = (float)(v >> 16);
-                            }
-                        };
-                        tap2(x0 + y0 + z0, c000, c100); tap2(x0 + y1 + z0, c010, c110);
-                        tap2(x0 + y0 + z1, c001, c101); tap2(x0 + y1 + z1, c011, c111);
-                    } else {
-                        c000 = tap(x0 + y0 + z0); c100 = tap(x1 + y0 + z0); c010 = tap(x0 + y1 + z0); c110 = tap(x1 + y1 + z0);
-                        c001 = tap(x0 + y0 + z1); c101 = tap(x1 + y0 + z1); c011 = tap(x0 + y1 + z1); c111 = tap(x1 + y1 + z1);
+                    auto tap2 = [&](uint32_t off, float &lo, float &hi) {
+                        if (sizeof(VoxelT) == 1) {
+                            const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+                            lo = (float)(v & 0xffu); hi = (float)(v >> 8);
+                        } else {
+                            const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(off << 1), 0, 0);
+                            lo = (float)(v & 0xffffu); hi = (float)(v >> 16);
+                        }
+                    };
+                    tap2(x0 + y0 + z0, c000, c100); tap2(x0 + y1 + z0, c010, c110);
+                    tap2(x0 + y0 + z1, c001, c101); tap2(x0 + y1 + z1, c011, c111);
+                    if (!pair) {
+                        c100 = tap(x1 + y0 + z0); c110 = tap(x1 + y1 + z0); c101 = tap(x1 + y0 + z1); c111 = tap(x1 + y1 + z1);
                     }
                 }
                 const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
