@@ -724,7 +724,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
 {
     L.tile_table = nullptr;
     L.tile_table_blocks = 0;
-    if (!tile_order || !fast_path_eligible(P, L)) return;
+    if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
     const uint64_t key = tileScheduleKey(P, rows);

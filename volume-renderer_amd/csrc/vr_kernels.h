@@ -9,6 +9,8 @@ namespace vr {
 
 // true when (P, L) runs on the specialised NEAREST/composite/iterative kernel
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L);
+// TRILINEAR in a grey mode with everything the batched trilinear kernel needs except the tile table
+bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L);
 
 // local image rows one launch covers (stripe padding included)
 int launch_local_rows(const FrameParams &P);

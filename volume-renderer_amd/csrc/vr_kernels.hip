@@ -899,6 +899,232 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
 #endif
 }
 
+// ------------------------------------------------------------------ trilinear kernel
+// TRILINEAR (GL's linear rule, fixed lerp order x, y, z -- oracle/vr_oracle.c) with the fast
+// kernel's skeleton: 8x8 pixels per wavefront, 512-thread workgroups in lockstep, longest-first
+// tile table, safe prefix without the six bound tests, checked tail, per-axis address tables in
+// LDS (X[i0], X[i1], Y[j0], ... : a neighbour across a brick boundary costs nothing extra).
+// Two samples (16 taps) are gathered per batch and software-pipelined.  Grey ramp, composite
+// (MIPM = 0) or MIP (MIPM = 1), iterative accumulation, alpha_scale in [0,1], 32-bit offsets.
+// Every sample goes through the generic kernel's operations in the generic kernel's order.
+#ifndef VR_EXP_TRI_BATCH
+#define VR_EXP_TRI_BATCH 2
+#endif
+constexpr int TRI_BATCH = VR_EXP_TRI_BATCH;
+
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool POW2, int MIPM>
+__global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, const VoxelT *__restrict__ vol,
+                                                           const uint32_t vol_bytes, float4 *__restrict__ fb,
+                                                           uint32_t *__restrict__ spp,
+                                                           const uint32_t *__restrict__ tile_table)
+{
+    __shared__ uint32_t axis_tab[FAST_AXIS_TAB_MAX];
+    const uint32_t t = tile_table[blockIdx.x];
+    if (t == 0xffffffffu) return;                            // padding block
+    const unsigned tx = t & 0xffffu, ty = t >> 16;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + (lane & 7u));
+    const int ly = (int)(ty * FAST_TILE_H + (wave >> 2) * 8u + (lane >> 3));
+    int px = lx, py;
+    if (P.stripe_count > 1) {
+        const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (st * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    const bool in_image = !(px >= P.col_lim || py >= P.row_lim || py >= P.row_end);
+    Ray ray = {};
+    float t_min = 0.0f, t_max = 0.0f;
+    bool hit = false;
+    if (in_image) {
+        ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+        hit = intersect_ray_aabb(P, ray, t_min, t_max);
+    }
+    if (__syncthreads_or(hit ? 1 : 0)) {
+        build_axis_tables<VoxelT, LAYOUT, false>(P, axis_tab, 512);
+        __syncthreads();
+    }
+    const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + P.nx, *tab_z = axis_tab + P.nx + P.ny;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
+
+    const float EPSILON = 0.000001f;
+    const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
+    float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
+    const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
+
+    // texcoord * dim of a position (before the -0.5 of the linear filter)
+    const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
+    float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;          // POW2: voxel-unit marching (see the fast kernel)
+    const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
+    const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+    auto scaled_texcoord = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
+        const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
+        const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
+        float uz = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);
+        uz = 1.0f - uz;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+        fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
+    };
+    // tap offsets (bytes) and the 3 lerp weights of the sample at scaled texcoord f: off[0..3] = the
+    // x0 taps of the four (y, z) corners, off[4..7] = their x1 neighbours; `pair` = x1 is the next
+    // storage element of x0 (same brick row / volume row), so one load fetches both
+    auto taps_of = [&](float fx, float fy, float fz, uint32_t (&off)[8], float &ax, float &ay, float &az, bool &pair) {
+        const float u = fx - 0.5f, v = fy - 0.5f, w = fz - 0.5f;
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        ax = u - fu; ay = v - fv; az = w - fw;
+        const int iu = (int)fu, iv = (int)fv, iw = (int)fw;
+        const int i0 = med3_i32(iu, 0, nxm1), i1 = med3_i32(iu + 1, 0, nxm1);
+        const int j0 = med3_i32(iv, 0, nym1), j1 = med3_i32(iv + 1, 0, nym1);
+        const int k0 = med3_i32(iw, 0, nzm1), k1 = med3_i32(iw + 1, 0, nzm1);
+        const uint32_t x0 = tab_x[i0], x1 = tab_x[i1], y0 = tab_y[j0], y1 = tab_y[j1], z0 = tab_z[k0], z1 = tab_z[k1];
+        pair = x1 == x0 + (uint32_t)sizeof(VoxelT);
+        off[0] = x0 + y0 + z0; off[1] = x0 + y1 + z0; off[2] = x0 + y0 + z1; off[3] = x0 + y1 + z1;
+        off[4] = x1 + y0 + z0; off[5] = x1 + y1 + z0; off[6] = x1 + y0 + z1; off[7] = x1 + y1 + z1;
+    };
+    // tv[0..3]: x0 tap in the low half, next storage element in the high half; tv[4..7]: the x1
+    // taps of the lanes whose x1 lies elsewhere (brick / volume edge)
+    auto load_taps = [&](const uint32_t (&off)[8], bool pair, uint32_t *tv) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            tv[k] = sizeof(VoxelT) == 1 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off[k], 0, 0)
+                                        : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off[k], 0, 0);
+        if (!pair) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                tv[4 + k] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[4 + k], 0, 0)
+                                                : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off[4 + k], 0, 0);
+        }
+    };
+    // interpolation, window and classification of one sample (the generic kernel's operations)
+    auto shade = [&](const uint32_t *tv, bool pair, float ax, float ay, float az, float &c, float &a) {
+        constexpr uint32_t M = sizeof(VoxelT) == 1 ? 0xffu : 0xffffu;
+        constexpr int SH = sizeof(VoxelT) == 1 ? 8 : 16;
+        const float c000 = (float)(tv[0] & M), c010 = (float)(tv[1] & M), c001 = (float)(tv[2] & M), c011 = (float)(tv[3] & M);
+        const float c100 = (float)(pair ? tv[0] >> SH : tv[4]), c110 = (float)(pair ? tv[1] >> SH : tv[5]);
+        const float c101 = (float)(pair ? tv[2] >> SH : tv[6]), c111 = (float)(pair ? tv[3] >> SH : tv[7]);
+        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+        float s = c0 + az * (c1 - c0);
+        s = fminf(fmaxf(s, P.fmin), P.fmax);                 // never NaN here
+        s = div_cert(s - P.fmin, P.fden, P.rden);
+        a = s * P.alpha_scale;
+        c = s * a;
+    };
+    float drgb = 0.0f, da = 0.0f;
+    auto accumulate = [&](float c, float a) {
+        if (MIPM == 1) {
+            if (da < a) da = a;
+        } else {
+            const float om = 1.0f - da;
+            drgb += c * om;
+            da += a * om;
+        }
+    };
+    int i = 0;
+    // gathers of one batch (TRI_BATCH consecutive samples); positions advance with the shader's additions
+    auto issue = [&](uint32_t (&tv)[TRI_BATCH * 8], float (&wt)[TRI_BATCH * 3], bool (&pr)[TRI_BATCH]) {
+        uint32_t off[TRI_BATCH][8];
+#pragma unroll
+        for (int u = 0; u < TRI_BATCH; u++) {
+            float fx, fy, fz;
+            if (POW2) {
+                const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+                fx = ux; fy = uy; fz = uz;
+                if (VIEW == 1) { fy = Sz - uz; fz = uy; }
+                else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                Qx += dSx; Qy += dSy; Qz += dSz;
+            } else {
+                scaled_texcoord(qx, qy, qz, fx, fy, fz);
+                qx += dsx; qy += dsy; qz += dsz;
+            }
+            taps_of(fx, fy, fz, off[u], wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], pr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < TRI_BATCH; u++) load_taps(off[u], pr[u], &tv[8 * u]);
+    };
+    // returns true when the ray terminated (see the fast kernel: batch early-termination)
+    auto consume = [&](const uint32_t (&tv)[TRI_BATCH * 8], const float (&wt)[TRI_BATCH * 3], const bool (&pr)[TRI_BATCH]) -> bool {
+        float c[TRI_BATCH], a[TRI_BATCH];
+#pragma unroll
+        for (int u = 0; u < TRI_BATCH; u++) shade(&tv[8 * u], pr[u], wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], c[u], a[u]);
+        const float drgb0 = drgb, da0 = da;
+        float da_last = 0.0f;
+#pragma unroll
+        for (int u = 0; u < TRI_BATCH; u++) {
+            if (u == TRI_BATCH - 1) da_last = da;
+            accumulate(c[u], a[u]);
+        }
+        if (da_last < 0.95f) { i += TRI_BATCH; return false; }
+        drgb = drgb0; da = da0;
+#pragma unroll
+        for (int u = 0; u < TRI_BATCH; u++) {
+            if (da >= 0.95f) return true;
+            accumulate(c[u], a[u]);
+            i++;
+        }
+        return da >= 0.95f;
+    };
+
+    bool done = false;
+    const int nb = k_safe / TRI_BATCH;
+    {
+        uint32_t va[TRI_BATCH * 8], vb[TRI_BATCH * 8];
+        float wa[TRI_BATCH * 3], wb[TRI_BATCH * 3];
+        bool pa[TRI_BATCH], pb[TRI_BATCH];
+        int b = 0;
+        bool fin = nb == 0;
+        if (!fin) issue(va, wa, pa);
+        for (;;) {
+            if (__syncthreads_and(fin ? 1 : 0)) break;
+#pragma unroll 1
+            for (int rep = 0; rep < 4 && !fin; rep++) {      // 16 samples between two lockstep votes
+                if (b + 1 < nb) issue(vb, wb, pb);
+                if (consume(va, wa, pa)) { done = true; fin = true; break; }
+                if (++b >= nb) { fin = true; break; }
+                if (b + 1 < nb) issue(va, wa, pa);
+                if (consume(vb, wb, pb)) { done = true; fin = true; break; }
+                if (++b >= nb) { fin = true; break; }
+            }
+        }
+    }
+    float tsx = dsx, tsy = dsy, tsz = dsz;
+    if (POW2) {
+        qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz;           // exact: S is a power of two
+        tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
+    }
+    // ---- checked tail: the shader's loop, literally
+    if (hit && !done) {
+        for (; i < P.max_steps; i++) {
+            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
+            uint32_t off[8], tv[8];
+            float ax, ay, az, c, a;
+            bool pair;
+            taps_of(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], off, ax, ay, az, pair);
+            load_taps(off, pair, tv);
+            shade(tv, pair, ax, ay, az, c, a);
+            accumulate(c, a);
+            qx += tsx; qy += tsy; qz += tsz;
+        }
+    }
+    if (!in_image) return;
+    const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+    if (MIPM == 1) store_pixel(P, fb, pix, da, da, da, da);
+    else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
+    if (spp) spp[pix] = (uint32_t)i;
+}
+
 // ------------------------------------------------------------------ relay kernel
 // A ray is a serial chain of ~1000 dependent samples; issued by ONE wavefront it advances at
 // ~300 cycles per sample, so a launch that cannot fill the chip's 8192 wave slots (one GPU's
@@ -1515,19 +1741,48 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
 }
 #endif
 
+// TRILINEAR through the batched kernel (host: tri_path_eligible)
+template <typename VoxelT, int LAYOUT>
+static hipError_t dispatch_tri(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb, uint32_t *spp,
+                               hipStream_t st)
+{
+    const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+    const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
+    const dim3 grid(L.tile_table_blocks), block(512);
+#define VR_TRI(TC, VW, P2, MP)                                                                                   \
+    do {                                                                                                         \
+        hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP>), grid, block, 0, st, P,          \
+                           (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table);                  \
+        return hipGetLastError();                                                                                \
+    } while (0)
+#define VR_TRI_V(TC, P2, MP)                                                                                     \
+    do {                                                                                                         \
+        if (view == 0) VR_TRI(TC, 0, P2, MP);                                                                    \
+        if (view == 1) VR_TRI(TC, 1, P2, MP);                                                                    \
+        VR_TRI(TC, 2, P2, MP);                                                                                   \
+    } while (0)
+    if (L.divmode_tc == DIV_CERT) { if (L.mip) VR_TRI_V(DIV_CERT, false, 1); VR_TRI_V(DIV_CERT, false, 0); }
+    if (pow2) { if (L.mip) VR_TRI_V(DIV_UNIT, true, 1); VR_TRI_V(DIV_UNIT, true, 0); }
+    if (L.mip) VR_TRI_V(DIV_UNIT, false, 1);
+    VR_TRI_V(DIV_UNIT, false, 0);
+#undef VR_TRI_V
+#undef VR_TRI
+}
+
 // ray-march launch of one (voxel type, layout) pair: the specialised kernels when `fast`, else
 // the generic one
 template <typename T, int LAY>
 static hipError_t raymarch_tu(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                              uint32_t *spp, int rows, bool fast, hipStream_t st)
+                              uint32_t *spp, int rows, int fast, hipStream_t st)
 {
-    if (fast) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);
+    if (fast == 1) return dispatch_fast<T, LAY>(P, L, vol, tf, fb, spp, rows, st);
+    if (fast == 2) return dispatch_tri<T, LAY>(P, L, vol, fb, spp, st);
     const unsigned tiles_x = (unsigned)((P.img_w + 15) / 16), tiles_y = (unsigned)((rows + 15) / 16);
     return spp ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)
                : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);
 }
 
-#define VR_TU_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, int rows, bool fast, hipStream_t st
+#define VR_TU_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, int rows, int fast, hipStream_t st
 #if VR_TU == 0
 hipError_t launch_raymarch_tu0(VR_TU_ARGS) { return raymarch_tu<uint8_t, 0>(P, L, vol, tf, fb, spp, rows, fast, st); }
 #elif VR_TU == 1
@@ -1551,6 +1806,17 @@ bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
            P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT &&
            P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f;
 }
+
+// TRILINEAR has a batched kernel for the grey modes: same preconditions as the fast path apart
+// from the filter, plus 32-bit offsets, address tables that fit LDS and a tile table
+bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L)
+{
+    return !L.generic && L.filter == 1 && P.accum == 0 && P.tf_len <= 1 && P.fden > 0.0f && P.max_val > P.min_val &&
+           L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT && P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f &&
+           !L.big_offsets && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
+}
+
+static bool tri_path_eligible(const FrameParams &P, const LaunchConfig &L) { return tri_path_candidate(P, L) && L.tile_table != nullptr; }
 
 int launch_local_rows(const FrameParams &P)
 {
@@ -1577,8 +1843,10 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
 {
     const int rows = launch_local_rows(P);   // local image rows covered by this launch
     if (rows <= 0 || P.img_w <= 0) return hipSuccess;
-    const bool fast = fast_path_eligible(P, L);
-    if (kernel_name) *kernel_name = !fast ? "raymarch_generic_kernel" : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel");
+    const int fast = fast_path_eligible(P, L) ? 1 : (tri_path_eligible(P, L) ? 2 : 0);
+    if (kernel_name)
+        *kernel_name = fast == 0 ? "raymarch_generic_kernel"
+                                 : (fast == 2 ? "raymarch_tri_kernel" : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel"));
     const int tu = (L.bytes_per_voxel == 1 ? 0 : 2) + (L.layout == 0 ? 0 : 1);
 #if VR_TU == -1
     switch (tu) {
