@@ -632,6 +632,56 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
     assert_same(got, want, what="u16 volume with a voxel > 4095")
 
 
+def test_trilinear_on_tiny_volumes_reads_the_last_voxel(vra, oracle):
+    """regression (found by tools/stress_campaign.py): the x-neighbour pair load of the LAST voxel
+    of the buffer reaches past it, and a partly out-of-range buffer load returns 0 for all of it"""
+    rng = np.random.default_rng(66)
+    R = vra.renderer
+    for dims in ((2, 3, 5), (1, 1, 1), (2, 2, 2), (5, 1, 3), (4, 4, 4)):
+        for dtype in (np.uint16, np.uint8):
+            vol = rand_volume(rng, dims, dtype)
+            vol.flat[-1] = vol.flat[0] = 255 if dtype == np.uint8 else 4000      # bright first and last voxel
+            spacing = (1.686, 0.836, 1.578)
+            for layout in (R.LAYOUT_LINEAR, R.LAYOUT_BRICKED):
+                for variant in (0, 1):
+                    with make_renderer(vra, (68, 68)) as r:
+                        r.setQuirks(0); r.setLayout(layout); r.setKernelVariant(variant)
+                        r.setVolume(vol, spacing); r.setFilter(R.FILTER_TRILINEAR)
+                        vmax = 255 if dtype == np.uint8 else 4095
+                        r.setWindow(vmax // 6, vmax); r.setAlpha(1.0)
+                        for _ in range(3):
+                            block = _random_camera_block(rng)
+                            r.setCameraBlock(block)
+                            r.render()
+                            got = r.readPixels()
+                            p = oracle.OracleParams(68, 68, cam=block, alpha_scale=1.0, voxel_size=spacing, min_val=vmax // 6,
+                                                    max_val=vmax, filter=1)
+                            want, _ = oracle.render(vol, p)
+                            assert_same(got, want, what=f"tiny trilinear dims {dims} {np.dtype(dtype).name} layout {layout} variant {variant} kernel {r.last_kernel_name}")
+
+
+def test_trilinear_kernel_full_size_equals_generic(vra, cfg3):
+    """cfg3 with TRILINEAR: the batched trilinear kernel against the line-by-line generic one,
+    composite and MIP, bit for bit (the oracle pins both at small sizes and in the goldens)"""
+    r = cfg3
+    R = vra.renderer
+    r.setFilter(R.FILTER_TRILINEAR)
+    try:
+        for mip in (False, True):
+            r.setMIP(mip)
+            r.setKernelVariant(0); r.render()
+            assert r.last_kernel_name == "raymarch_tri_kernel"
+            a = r.readPixels().copy()
+            na = r.countSamples()
+            r.setKernelVariant(1); r.render()
+            assert r.last_kernel_name == "raymarch_generic_kernel"
+            b = r.readPixels().copy()
+            nb = r.countSamples()
+            assert na == nb and np.array_equal(a.view(np.uint32), b.view(np.uint32)), mip
+    finally:
+        r.setMIP(False); r.setKernelVariant(0); r.setFilter(R.FILTER_NEAREST)
+
+
 def test_packed12_full_size_equals_unpacked(cfg3):
     """cfg3 (1024^3 u16 @1080p): packed and unpacked gathers give the same frame"""
     r = cfg3

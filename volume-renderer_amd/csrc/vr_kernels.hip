@@ -327,6 +327,20 @@ __device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx
     return k_safe;
 }
 
+// Size for the buffer descriptor of kernels that fetch an x-neighbour pair with one load: a
+// pair load on the LAST voxel of the buffer reaches 2 (u16) / 1 (u8) bytes past it, and a raw
+// buffer load that is partly out of range returns 0 for ALL of it.  The allocation carries
+// slack behind the volume (renderer_core.cpp: allocVolume), so the descriptor may cover 4
+// bytes more.
+__device__ __forceinline__ uint32_t pair_load_extent(uint32_t vol_bytes)
+{
+#ifdef VR_EXP_NO_PAIR_EXTENT      // experiment: reproduce the bug the regression test pins
+    return vol_bytes;
+#else
+    return vol_bytes > 0xfffffffbu ? vol_bytes : vol_bytes + 4u;
+#endif
+}
+
 // ------------------------------------------------------------------ generic kernel
 // One kernel that follows the shader line by line and takes every mode as a run-time
 // (wave-uniform) switch.  It is the correctness backbone: every configuration the
@@ -364,7 +378,7 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
     uint32_t fetches = 0;
     if (intersect_ray_aabb(P, ray, t_min, t_max)) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)vol_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, BIG ? 0 : (int)pair_load_extent(vol_bytes), 0x00020000);
         // per-axis terms of VoxelAddr<LAYOUT, false>::at(i, j, k) = X(i) + Y(j) + Z(k)  (mod 2^32)
         auto term_x = [&](int i) -> uint32_t {
             return LAYOUT == 0 ? (uint32_t)i : mad_u24((uint32_t)i >> BRICK_LX, 64u - (uint32_t)BRICK_X, (uint32_t)i);
@@ -945,7 +959,7 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         __syncthreads();
     }
     const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + P.nx, *tab_z = axis_tab + P.nx + P.ny;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)pair_load_extent(vol_bytes), 0x00020000);
 
     const float EPSILON = 0.000001f;
     const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
