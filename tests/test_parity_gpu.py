@@ -632,6 +632,36 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
     assert_same(got, want, what="u16 volume with a voxel > 4095")
 
 
+def test_long_axis_volume_without_address_tables(vra, oracle):
+    """nx + ny + nz > 3072: the LDS address tables (and with them the packed copy and the trilinear
+    kernel) do not apply; the specialised kernels compute brick addresses arithmetically"""
+    rng = np.random.default_rng(3072)
+    R = vra.renderer
+    dims = (3000, 40, 36)
+    vol = rand_volume(rng, dims, np.uint16, smooth=True)
+    spacing = (0.02, 1.0, 1.0)                                   # a box of sane proportions
+    for layout in (R.LAYOUT_BRICKED, R.LAYOUT_LINEAR):
+        for filt, mip in ((R.FILTER_NEAREST, False), (R.FILTER_NEAREST, True), (R.FILTER_TRILINEAR, False)):
+            with make_renderer(vra, (96, 64)) as r:
+                r.setQuirks(0); r.setLayout(layout); r.setVolume(vol, spacing)
+                r.setWindow(100, 3900); r.setAlpha(0.1); r.setFilter(filt); r.setMIP(mip)
+                r.cameraOrient(0.0, -0.3, 0.5)
+                block = r.getCameraBlock()
+                r.render()
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                kernel = r.last_kernel_name
+                assert r.pack12Bytes() == 0
+            p = oracle.OracleParams(96, 64, cam=block, alpha_scale=0.1, voxel_size=spacing, min_val=100, max_val=3900,
+                                    filter=int(filt == R.FILTER_TRILINEAR), is_mip=int(mip))
+            want, _, want_spp = oracle.render(vol, p, want_spp=True)
+            assert_same(got, want, spp, want_spp, what=f"long-axis volume layout {layout} filter {filt} mip {mip} kernel {kernel}")
+            if filt == R.FILTER_TRILINEAR:
+                assert kernel == "raymarch_generic_kernel"
+            else:
+                assert kernel in FAST_KERNELS
+
+
 def test_trilinear_on_tiny_volumes_reads_the_last_voxel(vra, oracle):
     """regression (found by tools/stress_campaign.py): the x-neighbour pair load of the LAST voxel
     of the buffer reaches past it, and a partly out-of-range buffer load returns 0 for all of it"""
