@@ -728,7 +728,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
     rng = np.random.default_rng(seed)
     dims_pool = [(1, 1, 1), (2, 3, 5), (8, 8, 8), (16, 32, 64), (31, 17, 9), (64, 64, 64), (50, 1, 50), (128, 4, 4)]
     if extended:
-        dims_pool += [(32, 32, 32), (7, 64, 33), (96, 80, 72), (4, 4, 128), (256, 16, 16)]
+        dims_pool += [(32, 32, 32), (7, 64, 33), (96, 80, 72), (4, 4, 128), (256, 16, 16), (3100, 3, 4)]   # the last: no address tables
     R = vra.renderer
     n_checked = 0
     for trial in range(n_trials):
