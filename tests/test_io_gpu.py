@@ -46,6 +46,36 @@ def test_raw_file_roundtrip_and_render(vra, oracle, tmp_path, dtype):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+def test_cfg2_sized_raw_file_through_the_reference_default_pipeline(vra, oracle, tmp_path):
+    """BASELINE config 2's shape end to end the way the reference does it: a 512x512x452 uint16
+    .raw + .raw.inf on disk (226 MB) -> readVolumeData -> default window = dataset range, +1000
+    quirk on (src/RendererCore.cpp:66-69,360-384) -> 1920x1080 frame; sparse rows against the oracle"""
+    dims = (512, 512, 452)
+    vol = oracle.gen_noise_ball(dims, 2, 0x9E3779B9)
+    raw = tmp_path / "head.raw"
+    raw.write_bytes(vol.tobytes())
+    (tmp_path / "head.raw.inf").write_text("#dimensions\n512 512 452\n\n#voxel-spacing\n1 1 1\n")
+    W, H = 1920, 1080
+    with make(vra, (W, H)) as r:
+        r.readVolumeData(raw, 2)
+        assert r.takeMessage() == ("File Loaded!", "File Loaded Successfully!")
+        d, _, b = r.dims
+        assert d == dims and b == 2
+        lo, hi = r.window
+        assert (lo, hi) == (int(vol.min()), int(vol.max())) == r.dataset_range
+        r.setAlpha(0.05)
+        r.render()
+        assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_relay_kernel")
+        got = r.readPixels()
+        block = r.getCameraBlock()
+    p = oracle.OracleParams(W, H, cam=block, alpha_scale=0.05, min_val=lo + 1000, max_val=hi + 1000, threads=0)
+    out = np.zeros((H, W, 4), dtype=np.float32)
+    for y in (150, 400, 540, 700, 930):
+        p.row_begin, p.row_end = y, y + 1
+        oracle.render(vol, p, out=out)
+        assert np.array_equal(got[y].view(np.uint32), out[y].view(np.uint32)), y
+
+
 def test_pvm_file_to_device_and_render(vra, oracle):
     cases = {c["file"]: c for c in json.loads((GOLDEN / "pvm_manifest.json").read_text())}
     c = cases["pvm2_u16_8x6x4_scaled.pvm"]
