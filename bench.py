@@ -447,6 +447,16 @@ def extras(args, r, local, stream):
     r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)
     timed("offaxis_deep")
     r.resetCamera()
+    # interactive use: the camera moves every frame (GUI orbit), host work included (wall clock)
+    r.render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r.cameraOrient(0.0, 0.0, 0.002)
+        r.renderAsync()
+    torch.cuda.synchronize()
+    out["orbiting_camera_wall_ms_per_frame"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    r.resetCamera()
     return out
 
 

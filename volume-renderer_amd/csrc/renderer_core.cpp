@@ -727,8 +727,14 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
-    const uint64_t key = tileScheduleKey(P, rows);
-    if (key != tile_table_key_ || !d_tile_table_) {
+    // The table must list exactly the tiles of this image / shard (shape key); the camera only
+    // decides their ORDER, a speed heuristic.  While the camera moves (GUI orbit: every frame) the
+    // cached order is kept until the camera block has drifted noticeably, so that the host-side
+    // rebuild + upload (~0.7 ms at 1080p) is not paid per frame.
+    const uint64_t shape_key = tileScheduleKey(P, rows, false);
+    float drift = 0.0f;
+    for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
+    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table);
         if (table.size() > tile_table_capacity_) {
@@ -740,7 +746,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
         check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
         check(hipMemcpy(d_tile_table_, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
         tile_table_blocks_ = table.size();
-        tile_table_key_ = key;
+        tile_table_key_ = shape_key;
+        std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;

@@ -138,6 +138,7 @@ private:
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
+    float tile_table_cam_[21] = {};          // camera block the cached order was built for
     unsigned tile_active_ = 0;               // tiles with work in the cached schedule
     void refreshTileSchedule(const FrameParams &P, LaunchConfig &L);
     const char *last_kernel_ = "";

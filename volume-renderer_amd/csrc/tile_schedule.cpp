@@ -46,14 +46,14 @@ int globalRow(const FrameParams &P, int ly)
 
 }  // namespace
 
-uint64_t tileScheduleKey(const FrameParams &P, int rows)
+uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
 {
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void *p, size_t n) {
         const unsigned char *b = static_cast<const unsigned char *>(p);
         for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; }
     };
-    mix(P.cam, sizeof(P.cam));
+    if (with_camera) mix(P.cam, sizeof(P.cam));
     mix(&P.img_w, sizeof(int32_t) * 9);      // img_w .. stripe_count (contiguous int32 fields)
     mix(P.pmin, sizeof(P.pmin)); mix(P.pmax, sizeof(P.pmax));
     mix(&P.step, sizeof(P.step)); mix(&P.max_steps, sizeof(P.max_steps));

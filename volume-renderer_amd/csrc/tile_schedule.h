@@ -23,7 +23,8 @@ constexpr uint32_t kTilePadding = 0xffffffffu;
 // returns the number of tiles with a non-zero work estimate
 unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table);
 
-// cheap fingerprint of everything the schedule depends on
-uint64_t tileScheduleKey(const FrameParams &P, int rows);
+// cheap fingerprint of everything the schedule depends on; with_camera = false: of everything
+// that decides WHICH tiles exist (image, shard, volume box) -- the camera only decides their order
+uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera = true);
 
 }  // namespace vr
