@@ -16,3 +16,15 @@ for i in range(50):
     r.render()
 t1 = time.perf_counter(); k = r.kernelMsTake()
 print(f"orbiting camera: {(t1-t0)/50*1e3:.3f} ms/frame wall, kernel {k/50:.3f} ms")
+t0 = time.perf_counter()
+for i in range(50):
+    r.setWindow(0, 4095 - i)             # drag the window slider: a new divisor every frame
+    r.render()
+t1 = time.perf_counter(); k = r.kernelMsTake()
+print(f"window slider: {(t1-t0)/50*1e3:.3f} ms/frame wall, kernel {k/50:.3f} ms")
+t0 = time.perf_counter()
+for i in range(50):
+    r.setAlpha(0.004 + 1e-5 * i)
+    r.render()
+t1 = time.perf_counter(); k = r.kernelMsTake()
+print(f"alpha slider: {(t1-t0)/50*1e3:.3f} ms/frame wall, kernel {k/50:.3f} ms")
