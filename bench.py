@@ -437,6 +437,12 @@ def extras(args, r, local, stream):
         r.renderAsync()
         r.readPixels()
     out["frame_plus_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
+    r.readPixelsRGBA8()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        r.renderAsync()
+        r.readPixelsRGBA8()
+    out["frame_plus_rgba8_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
     r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
     r.setAlpha(1.0)
     timed("shallow_alpha1_ert")

@@ -190,6 +190,10 @@ float vr_kernel_ms_take(vr_handle h);
 int vr_count_samples(vr_handle h, uint64_t *total, uint32_t *per_pixel, size_t n_pixels);
 void *vr_framebuffer_device(vr_handle h);
 int vr_read_pixels(vr_handle h, float *rgba, size_t n_floats);     /* D2H of the target */
+/* the same frame as RGBA8 (fb_w*fb_h*4 bytes, row 0 = bottom like the target), converted on the
+   device with glReadPixels' rule round(clamp(c,0,1)*255) (the precision of the reference's own
+   read-back, src/RendererCore.cpp:170): a quarter of the bytes over PCIe for display */
+int vr_read_pixels_rgba8(vr_handle h, unsigned char *rgba8, size_t n_bytes);
 /* saveImage(fn, ext) (src/RendererCore.cpp:165-182): ext ".png" | ".jpg" (quality 100, as
    :177) | ".bmp" of the reference's dialog (RendererGUI.cpp:221), plus ".ppm" */
 int vr_save_image(vr_handle h, const char *path, const char *ext);

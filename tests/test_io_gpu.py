@@ -137,6 +137,7 @@ def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
         r.setAlpha(0.5)
         r.render()
         frame = r.readPixels()
+        rgba8 = r.readPixelsRGBA8()              # device-side conversion, glReadPixels' rule
         for ext in (".png", ".bmp", ".ppm", ".jpg"):
             assert r.saveImage(tmp_path / f"shot{ext}", ext)
         assert not r.saveImage(tmp_path / "shot.gif", ".gif")
@@ -144,6 +145,7 @@ def test_save_image_png_bmp_ppm(vra, oracle, tmp_path):
     for ext in (".png", ".bmp", ".ppm"):
         img = np.asarray(Image.open(tmp_path / f"shot{ext}").convert("RGB"))
         assert img.shape == (52, 77, 3) and np.array_equal(img, want), ext
+    assert np.array_equal(rgba8[::-1, :, :3], want) and np.array_equal(rgba8[..., 3], np.floor(np.clip(frame[..., 3], 0, 1) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8))
     jpg = np.asarray(Image.open(tmp_path / "shot.jpg").convert("RGB")).astype(np.int32)      # quality 100, 4:4:4
     assert jpg.shape == (52, 77, 3) and np.abs(jpg - want.astype(np.int32)).max() <= 3
 

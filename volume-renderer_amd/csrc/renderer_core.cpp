@@ -48,6 +48,7 @@ RendererCore::~RendererCore()
         if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
+        if (d_rgba8_) (void)hipFree(d_rgba8_);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
         if (own_stream_) (void)hipStreamDestroy(own_stream_);
@@ -817,6 +818,24 @@ void RendererCore::readPixels(float *rgba, size_t n_floats)
     const void *src = framebufferDevice();
     if (!src) throw std::runtime_error("readPixels: no framebuffer");
     check(hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H framebuffer)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+}
+
+void RendererCore::readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes)
+{
+    requireDevice("readPixelsRGBA8");
+    const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1];
+    if (!rgba8 || n_bytes < n * 4) throw std::invalid_argument("readPixelsRGBA8: buffer too small");
+    if (ext_fb_ && fb_format_ == 1) throw std::invalid_argument("readPixelsRGBA8: the (grey, alpha) target has no RGBA form on the device");
+    const void *src = framebufferDevice();
+    if (!src) throw std::runtime_error("readPixelsRGBA8: no framebuffer");
+    if (rgba8_capacity_ < n * 4) {
+        if (d_rgba8_) { (void)hipFree(d_rgba8_); d_rgba8_ = nullptr; rgba8_capacity_ = 0; }
+        check(hipMalloc(&d_rgba8_, n * 4), "hipMalloc(rgba8)");
+        rgba8_capacity_ = n * 4;
+    }
+    check(launch_to_rgba8(src, d_rgba8_, n, stream()), "to_rgba8_kernel");
+    check(hipMemcpyAsync(rgba8, d_rgba8_, n * 4, hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H rgba8)");
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
 }
 

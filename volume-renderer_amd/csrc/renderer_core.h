@@ -53,6 +53,7 @@ public:
     void readVolumeData(std::string fn);     // :242-447
     bool checkRawInfFile(std::string fn);    // :46-54
     bool saveImage(std::string fn, std::string ext);  // :165-182
+    void readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes);   // the own target converted on the device: 4x fewer bytes over PCIe
     bool loadShader(std::string fn, bool reload);     // :112-136
 
     Camera main_cam;
@@ -128,6 +129,8 @@ private:
     int fb_format_ = 0;
     std::map<uint32_t, bool> cert_cache_;    // divisor bits -> certified
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
+    void *d_rgba8_ = nullptr;                // RGBA8 staging of the target (readPixelsRGBA8)
+    size_t rgba8_capacity_ = 0;
     void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)
     size_t vol12_bytes_ = 0;
     bool vol12_failed_ = false;              // allocation of the packed copy failed for this volume: do not retry

@@ -423,6 +423,11 @@ int vr_read_pixels(vr_handle h, float *rgba, size_t n_floats)
     return guarded(h, [&](vr::RendererCore &c) { c.readPixels(rgba, n_floats); });
 }
 
+int vr_read_pixels_rgba8(vr_handle h, unsigned char *rgba8, size_t n_bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.readPixelsRGBA8(rgba8, n_bytes); });
+}
+
 int vr_save_image(vr_handle h, const char *path, const char *ext)
 {
     if (!h) return VR_E_INVALID;

@@ -1917,6 +1917,27 @@ hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStr
     return hipGetLastError();
 }
 
+// RGBA32F target -> RGBA8 (display / screenshot precision): glReadPixels' float -> unorm8 rule,
+// round(clamp(c, 0, 1) * 255), NaN -> 0; row order unchanged
+__global__ __launch_bounds__(256) void to_rgba8_kernel(const float4 *__restrict__ fb, uint32_t *__restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = fb[i];
+    auto q = [](float v) -> uint32_t {
+        v = v != v ? 0.0f : fminf(fmaxf(v, 0.0f), 1.0f);
+        return (uint32_t)floorf(v * 255.0f + 0.5f);
+    };
+    out[i] = q(c.x) | (q(c.y) << 8) | (q(c.z) << 16) | (q(c.w) << 24);
+}
+
+hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pixels, hipStream_t st)
+{
+    hipLaunchKernelGGL(to_rgba8_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, st, (const float4 *)fb_rgba32f,
+                       (uint32_t *)out_rgba8, pixels);
+    return hipGetLastError();
+}
+
 // streaming read of a device buffer with 16-byte loads: the box's achievable HBM read rate,
 // measured next to the ray-march (vr_measure_stream_read)
 __global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16, unsigned *sink)

@@ -134,6 +134,7 @@ def load_library() -> C.CDLL:
         "vr_count_samples": (i32, [h, C.POINTER(u64), C.POINTER(u32), C.c_size_t]),
         "vr_framebuffer_device": (C.c_void_p, [h]),
         "vr_read_pixels": (i32, [h, C.POINTER(f32), C.c_size_t]),
+        "vr_read_pixels_rgba8": (i32, [h, C.c_void_p, C.c_size_t]),
         "vr_save_image": (i32, [h, C.c_char_p, C.c_char_p]),
         "vr_last_kernel_name": (C.c_char_p, [h]),
         "vr_read_pvm_volume": (C.c_void_p, [C.c_char_p] + [C.POINTER(C.c_uint)] * 4 + [C.POINTER(f32)] * 3),
@@ -442,6 +443,13 @@ class RendererCore:
         w, h = self.framebuffer_size
         out = np.zeros((h, w, 4), dtype=np.float32)
         self._check(self._lib.vr_read_pixels(self._h, _fp(out), out.size))
+        return out
+
+    def readPixelsRGBA8(self) -> np.ndarray:
+        """the frame as uint8 [H, W, 4] (row 0 = bottom), converted on the device"""
+        w, h = self.framebuffer_size
+        out = np.empty((h, w, 4), dtype=np.uint8)
+        self._check(self._lib.vr_read_pixels_rgba8(self._h, out.ctypes.data, out.size))
         return out
 
     def saveImage(self, fn, ext) -> bool:
