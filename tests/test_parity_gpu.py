@@ -186,10 +186,17 @@ def test_transfer_function(vra, oracle):
         r.setKernelVariant(1)
         r.render()
         assert np.array_equal(got.view(np.uint32), r.readPixels().view(np.uint32))
-        r.setMIP(True)                                           # MIP + TF has no fast variant
+        r.setMIP(True)                                           # MIP through the transfer function (MODE 3)
         r.setKernelVariant(0)
         r.render()
+        assert r.last_kernel_name in FAST_KERNELS
+        mip_fast = r.readPixels()
+        r.setKernelVariant(1)
+        r.render()
         assert r.last_kernel_name == "raymarch_generic_kernel"
+        assert np.array_equal(mip_fast.view(np.uint32), r.readPixels().view(np.uint32))
+        want_mip, _ = oracle.render(vol, oracle.OracleParams(90, 70, alpha_scale=0.2, tf_rgba=lut, is_mip=1))
+        assert_same(mip_fast, want_mip, what="MIP through the transfer function")
     want_lut = oracle.spline_tf(iso, rgba)
     assert np.array_equal(lut.view(np.uint32), want_lut.view(np.uint32))
     want, _ = oracle.render(vol, oracle.OracleParams(90, 70, alpha_scale=0.2, tf_rgba=want_lut))
@@ -743,7 +750,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
         mip = tf = tri = accum = relay = stripes = False
         if extended:
             mode = int(rng.integers(0, 12))
-            mip, tf, tri, accum = mode == 1, mode == 2, mode == 3, mode == 4
+            mip, tf, tri, accum = mode in (1, 8), mode in (2, 8), mode == 3, mode == 4     # 8: MIP through the transfer function
             relay = mode in (5, 6)
             stripes = mode == 7
             if rng.random() < 0.2:

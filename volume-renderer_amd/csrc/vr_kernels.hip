@@ -610,7 +610,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
             for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
                 const float v = div_cert(s - P.fmin, P.fden, P.rden);
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     // classification through the transfer function: index = round(v*(len-1)) here,
                     // src.a *= alpha_scale, src.rgb *= src.a in the 256-entry table below
                     int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
@@ -621,11 +621,16 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
                     lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
                 }
             }
-            if (LUT && MODE == 2) {
+            if (LUT && MODE >= 2) {
                 for (int e = (int)threadIdx.x; e < P.tf_len; e += (int)FAST_THREADS) {
                     const float4 t = tf[e];
                     const float a = t.w * P.alpha_scale;
-                    lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a; lut[4 * e + 3] = a;
+                    if (MODE == 3) {            // MIP(): s *= alpha_scale on all four channels (VolumeRenderer.cs:164)
+                        lut[4 * e + 0] = t.x * P.alpha_scale; lut[4 * e + 1] = t.y * P.alpha_scale; lut[4 * e + 2] = t.z * P.alpha_scale;
+                    } else {                    // composite: src.a *= alpha_scale, src.rgb *= src.a (:130-131)
+                        lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a;
+                    }
+                    lut[4 * e + 3] = a;
                 }
             }
             __syncthreads();
@@ -662,14 +667,14 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         };
         constexpr int LUT_SHIFT = 3;
         // byte offset of entry 0 relative to texel*entry_bytes (MODE 2: of index byte 0 relative to texel)
-        const int lut_bias = MODE == 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
+        const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
         // window + classification of one texel -> premultiplied colour c (cg, cb only in MODE 2)
         // and opacity a of VolumeRenderer.cs:130-131
         auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
             if (LUT) {
                 int t = (int)texel;
                 if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);   // clamp(texel, min_val, max_val), min <= max
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[(uint32_t)(t + lut_bias)];
                     const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
                     c = q.x; cg = q.y; cb = q.z; a = q.w;
@@ -797,6 +802,8 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         auto accumulate = [&](float c, float cg, float cb, float a) {
             if (MODE == 1) {
                 if (da < a) da = a;                          // dest = src when dest.a < src.a (:165-168)
+            } else if (MODE == 3) {
+                if (da < a) { drgb = c; dg = cg; db = cb; da = a; }
             } else {
                 const float om = 1.0f - da;
                 drgb += c * om;
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    if (MODE == 2) store_pixel(P, fb, pix, drgb, dg, db, da);
+    if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
 #ifdef VR_EXP_TRACE
@@ -1699,16 +1706,16 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
 #define VR_LAUNCH(TC, LT, P2, NC) (noskip ? VR_LAUNCH2(TC, LT, P2, NC, !HEADLINE) : VR_LAUNCH2(TC, LT, P2, NC, true))
     if (L.divmode_tc == DIV_CERT) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_CERT, true, false, true) : VR_LAUNCH(DIV_CERT, true, false, false);
-        if (MODE != 2) return VR_LAUNCH(DIV_CERT, false, false, false);
+        if (MODE < 2) return VR_LAUNCH(DIV_CERT, false, false, false);
         return hipErrorInvalidValue;
     }
     if (pow2) {
         if (lut) return noclamp ? VR_LAUNCH(DIV_UNIT, true, true, true) : VR_LAUNCH(DIV_UNIT, true, true, false);
-        if (MODE != 2) return VR_LAUNCH(DIV_UNIT, false, true, false);
+        if (MODE < 2) return VR_LAUNCH(DIV_UNIT, false, true, false);
         return hipErrorInvalidValue;
     }
     if (lut) return noclamp ? VR_LAUNCH(DIV_UNIT, true, false, true) : VR_LAUNCH(DIV_UNIT, true, false, false);
-    if (MODE != 2) return VR_LAUNCH(DIV_UNIT, false, false, false);
+    if (MODE < 2) return VR_LAUNCH(DIV_UNIT, false, false, false);
     return hipErrorInvalidValue;
 #undef VR_LAUNCH
 #undef VR_LAUNCH2
@@ -1718,6 +1725,7 @@ template <typename VoxelT, int LAYOUT, int VIEW, bool BIG>
 static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                                  float4 *fb, uint32_t *spp, int rows, hipStream_t st)
 {
+    if (L.mip && P.tf_len > 1) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 3>(P, L, vol, tf, fb, spp, rows, st);
     if (L.mip) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 1>(P, L, vol, tf, fb, spp, rows, st);
     if (P.tf_len > 1) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 2>(P, L, vol, tf, fb, spp, rows, st);
     return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 0>(P, L, vol, tf, fb, spp, rows, st);
@@ -1815,7 +1823,7 @@ hipError_t launch_raymarch_tu3(VR_TU_ARGS) { return raymarch_tu<uint16_t, 1>(P, 
 bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L)
 {
     const bool tf = P.tf_len > 1;
-    if (tf && (L.mip || !L.use_lut)) return false;
+    if (tf && !L.use_lut) return false;
     return !L.generic && L.filter == 0 && P.accum == 0 && P.fden > 0.0f &&
            P.max_val > P.min_val && L.divmode_win == DIV_CERT && L.divmode_tc != DIV_EXACT &&
            P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f;
