@@ -18,6 +18,11 @@ BASELINE.json's metric.  `roofline` uses the algorithmic bytes of SURVEY 8(d):
 S*b + W*H*16 per launch over the kernel's average launch duration measured with HIP
 events on the launch stream.  `cpu_baseline` is the scalar oracle (oracle/vr_oracle.c,
 "port") timed on this box's host cores on a bounded row sample of the same frame.
+
+Set-up (untimed, like generating the volume) ends with --clock-ramp-frames frames (default
+150, ~75 ms): an idle MI355X reaches its sustained clocks only after ~50 ms of load, and the
+metric is the sustained rate of a renderer that is running.  Then W warm-up steps, a barrier,
+EXACTLY K timed steps, a barrier.  `config.clock_ramp_frames` records it; 0 switches it off.
 """
 from __future__ import annotations
 
@@ -39,8 +44,11 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--clock-ramp-frames", type=int, default=150,
+                    help="untimed frames rendered during set-up, before the W warm-up steps: an idle MI355X needs "
+                         "~50 ms of load to reach its sustained clocks (the first ~25 frames run ~15 %% slower)")
     ap.add_argument("--volume", type=int, default=1024, help="synthetic volume edge (voxels)")
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="non-cubic synthetic volume NX NY NZ (overrides --volume)")
     ap.add_argument("--bytes", type=int, default=2, choices=(1, 2))
@@ -196,6 +204,9 @@ def main():
             torch.cuda.synchronize(dev)
 
     frame = None
+    for _ in range(max(args.clock_ramp_frames, 0)):     # set-up: bring the GPU to its sustained clocks
+        frame = step()
+    barrier()
     for _ in range(args.warmup):
         frame = step()
     barrier()
@@ -265,6 +276,7 @@ def main():
                              + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
                              + (" + RCCL all_gather of (grey, alpha) shards" if grey_alpha else " + RCCL all_gather"),
                 "kernel": r.last_kernel_name,
+                "clock_ramp_frames": max(args.clock_ramp_frames, 0),
             },
             "roofline": {
                 "bound": "hbm",
