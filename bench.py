@@ -263,7 +263,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 compositing over u%d voxels" % (8 * b),
+            "dtype": "f32",                                   # the arithmetic type of the path (voxels: config.voxel_dtype)
             "data": "synthetic",
             "config": {
                 "workload": f"synthetic noise-ball {'x'.join(map(str, dims))} uint{8 * b} (generated in HBM, seed 0x9E3779B9), "
@@ -276,6 +276,7 @@ def main():
                              + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
                              + (" + RCCL all_gather of (grey, alpha) shards" if grey_alpha else " + RCCL all_gather"),
                 "kernel": r.last_kernel_name,
+                "voxel_dtype": "u%d" % (8 * b),
                 "clock_ramp_frames": max(args.clock_ramp_frames, 0),
             },
             "roofline": {
