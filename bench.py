@@ -79,6 +79,8 @@ def parse_args():
 def main():
     args = parse_args()
     import numpy as np
+    # the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
