@@ -2,7 +2,10 @@
 """bench.py -- the ray-march hot path on BASELINE.json's headline workload.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N>1 works both ways: launched by torch.distributed.run (one rank per GPU, RANK / LOCAL_RANK /
+  WORLD_SIZE / MASTER_* from the environment), or as the plain command above -- bench.py then
+  starts the N ranks itself (re-executing itself under torch.distributed.run on 127.0.0.1) and
+  still prints exactly ONE JSON line.
 
 A "step" is one frame: one launch of the ray-march kernel over this rank's image-row
 shard, plus (N>1) the RCCL all_gather + de-interleave that puts the whole frame on every
@@ -72,12 +75,49 @@ def parse_args():
                     help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
-    ap.add_argument("--extras", action="store_true", help="also time the secondary regimes (shallow / trilinear)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time the slow secondary measurements (PCIe read-back, orbiting camera); the secondary "
+                         "kernel regimes (unpacked, shallow, off-axis, trilinear) are always in `extras` at N=1")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary kernel regimes")
+    ap.add_argument("--dataset", default=None,
+                    help="render a volume file (.raw + .raw.inf, or .pvm) instead of the synthetic volume; --bytes gives its "
+                         "voxel size.  VR_DATA_BONSAI / VR_DATA_HEAD name the reference's two datasets (README.md:6-7) for "
+                         "--dataset bonsai / --dataset head")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, RCCL over
+    xGMI) by re-executing this file under torch.distributed.run, forward rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] the {args.gpus}-rank run failed (exit code {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))      # before torch / HIP are touched in this process
     import numpy as np
     # the host driver only supports dmabuf IPC: RCCL / cross-process device memory need this
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -87,8 +127,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
@@ -122,8 +160,18 @@ def main():
     r.setQuirks(0)   # explicit window below is what the kernel sees (no +1000, no truncated grid)
     r.setLayout(R.LAYOUT_BRICKED if args.layout == "bricked" else R.LAYOUT_LINEAR)
     dims = tuple(args.dims) if args.dims else (N, N, N)
-    r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
-    win = tuple(args.window) if args.window else (0, vmax)
+    dataset = args.dataset
+    if dataset in ("bonsai", "head"):            # the reference's datasets, when supplied on the box
+        dataset = os.environ.get("VR_DATA_BONSAI" if dataset == "bonsai" else "VR_DATA_HEAD")
+        if not dataset:
+            raise SystemExit("--dataset bonsai/head needs VR_DATA_BONSAI / VR_DATA_HEAD to name the file")
+    if dataset:
+        r.readVolumeData(dataset, b)
+        dims = tuple(r.dims[0])
+        win = tuple(args.window) if args.window else r.window
+    else:
+        r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
+        win = tuple(args.window) if args.window else (0, vmax)
     r.setWindow(*win)
     if args.tf:   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59), black->white ramp
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
@@ -245,6 +293,9 @@ def main():
         t = torch.tensor([1 if gather_ok else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gather_ok = bool(t.item())
+        t = torch.tensor([1], dtype=torch.int64, device=dev)     # ranks counted by the communicator itself
+        dist.all_reduce(t)
+        n_ranks_seen = int(t.item())
 
     result = None
     if rank == 0:
@@ -268,8 +319,9 @@ def main():
             "dtype": "f32",                                   # the arithmetic type of the path (voxels: config.voxel_dtype)
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic noise-ball {'x'.join(map(str, dims))} uint{8 * b} (generated in HBM, seed 0x9E3779B9), "
-                            f"{W}x{H} RGBA32F, reference default camera" + (" (off-axis pose)" if args.pose != "default" else "")
+                "workload": (f"file {Path(dataset).name} " if dataset else "synthetic noise-ball ") + f"{'x'.join(map(str, dims))} uint{8 * b} "
+                            + ("" if dataset else "(generated in HBM, seed 0x9E3779B9), ")
+                            + f"{W}x{H} RGBA32F, reference default camera" + (" (off-axis pose)" if args.pose != "default" else "")
                             + f", {args.filter.upper()} filter, window [{win[0]},{win[1]}], alpha_scale {args.alpha}, "
                             + ("transfer function, " if args.tf else "") + ("empty-space skipping, " if args.skip_empty else "")
                             + f"iterative accumulation, {args.layout} layout",
@@ -309,11 +361,12 @@ def main():
                 print(f"[bench] stream-read probe failed: {exc}", file=sys.stderr)
         if world > 1:
             result["multi_gpu_frame_bit_exact"] = gather_ok
+            result["n_ranks_seen"] = n_ranks_seen
             result["overlap"] = "all_gather of frame i on a second stream overlaps the kernel of frame i+1"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
-        if world == 1 and args.extras:
-            result["extras"] = extras(args, r, local, stream)
+        if world == 1 and not args.no_extras and not args.shard:
+            result["extras"] = extras(args, r, local, stream, b, W, H)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -328,18 +381,33 @@ def plan_pixels(plan, W):
     return int((plan.global_rows() >= 0).sum()) * W
 
 
+def kernel_source_hash() -> str:
+    """SHA-256 over the kernel sources: a PMC traffic figure is only quoted for the kernels it was
+    measured on (tools/pmc_traffic.py stores the same hash next to each figure)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "volume-renderer_amd" / "csrc").glob("*.hip")) + sorted((ROOT / "volume-renderer_amd" / "csrc").glob("vr_frame.h")):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(args, world):
     """HBM bytes per launch from the committed PMC profile of this same command
-    (profiles/traffic.json, written by tools/pmc_traffic.py), or null."""
+    (profiles/traffic.json, written by tools/pmc_traffic.py), or null -- also null when the
+    kernels have changed since the counters were collected (source hash mismatch)."""
     p = ROOT / "profiles" / "traffic.json"
     if world != 1 or not p.exists():
         return None
     try:
         d = json.loads(p.read_text())
-        if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default":
+        if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12:
             return None
         key = f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
-        return d.get(key)
+        entry = d.get(key)
+        if isinstance(entry, dict):
+            return entry.get("bytes") if entry.get("kernel_source_hash") == kernel_source_hash() else None
+        return None          # legacy entry without a source hash: cannot be attributed to these kernels
     except Exception:
         return None
 
@@ -419,19 +487,22 @@ def cpu_baseline(args, r, frame, gpu_msamples):
     }
 
 
-def extras(args, r, local, stream):
-    """secondary regimes, timed the same way (kernel only, single GPU)"""
+def extras(args, r, local, stream, b, W, H):
+    """secondary regimes of the same workload, timed the same way (kernel only, HIP events on the
+    launch stream, single GPU), each with its own roofline fraction (algorithmic bytes S*b + W*H*16
+    of THAT regime): the headline without the 12-bit packed copy, the shallow (early-ray-termination)
+    regime, the off-axis pose and TRILINEAR filtering"""
     import torch
 
     vra = importlib.import_module("volume-renderer_amd")
     R = vra.renderer
     out = {}
 
-    def timed(name, steps=10):
+    def timed(name, steps=20):
         r.setFramebufferExternal(0); r.setFramebufferCompact(False)
         s = r.countSamples()
         r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
-        for _ in range(3):
+        for _ in range(5):
             r.renderAsync()
         torch.cuda.synchronize()
         a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -441,43 +512,53 @@ def extras(args, r, local, stream):
         c.record(stream)
         torch.cuda.synchronize()
         ms = a.elapsed_time(c) / steps
+        gbps = (s * b + W * H * 16) / (ms * 1e-3) / 1e9
         out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
-                     "mpixels_per_s": round(args.width * args.height / ms / 1e3, 1), "kernel": r.last_kernel_name}
+                     "mpixels_per_s": round(W * H / ms / 1e3, 1), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4),
+                     "kernel": r.last_kernel_name}
 
-    # PCIe-inclusive: kernel + D2H of the finished RGBA32F frame (vr_read_pixels), for DESIGN.md
-    r.setFramebufferExternal(0); r.setFramebufferCompact(False)
-    r.render(); r.readPixels()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        r.renderAsync()
-        r.readPixels()
-    out["frame_plus_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
-    r.readPixelsRGBA8()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        r.renderAsync()
+    if args.extras:
+        # PCIe-inclusive: kernel + D2H of the finished RGBA32F frame (vr_read_pixels), for DESIGN.md
+        r.setFramebufferExternal(0); r.setFramebufferCompact(False)
+        r.render(); r.readPixels()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.renderAsync()
+            r.readPixels()
+        out["frame_plus_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
         r.readPixelsRGBA8()
-    out["frame_plus_rgba8_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
-    r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.renderAsync()
+            r.readPixelsRGBA8()
+        out["frame_plus_rgba8_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
+        r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
+    if b == 2 and not args.no_pack12 and r.pack12Bytes():
+        r.setPack12(False)
+        timed("headline_without_pack12")       # general 16-bit data (voxels above 4095 somewhere)
+        r.setPack12(True)
     r.setAlpha(1.0)
     timed("shallow_alpha1_ert")
     r.setAlpha(args.alpha)
-    r.setFilter(R.FILTER_TRILINEAR)
-    timed("trilinear_deep", steps=5)
-    r.setFilter(R.FILTER_NEAREST)
-    r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)
-    timed("offaxis_deep")
-    r.resetCamera()
-    # interactive use: the camera moves every frame (GUI orbit), host work included (wall clock)
-    r.render()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        r.cameraOrient(0.0, 0.0, 0.002)
-        r.renderAsync()
-    torch.cuda.synchronize()
-    out["orbiting_camera_wall_ms_per_frame"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
-    r.resetCamera()
+    if args.filter == "nearest":
+        r.setFilter(R.FILTER_TRILINEAR)
+        timed("trilinear_deep", steps=10)
+        r.setFilter(R.FILTER_NEAREST)
+    if args.pose == "default":
+        r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)
+        timed("offaxis_deep", steps=10)
+        r.resetCamera()
+    if args.extras:
+        # interactive use: the camera moves every frame (GUI orbit), host work included (wall clock)
+        r.render()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r.cameraOrient(0.0, 0.0, 0.002)
+            r.renderAsync()
+        torch.cuda.synchronize()
+        out["orbiting_camera_wall_ms_per_frame"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+        r.resetCamera()
     return out
 
 

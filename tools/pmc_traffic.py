@@ -20,7 +20,7 @@ from pathlib import Path
 summary, key = sys.argv[1], sys.argv[2]
 vals = {}
 for line in Path(summary).read_text().splitlines():
-    if "raymarch_fast_kernel" not in line and "raymarch_generic_kernel" not in line:
+    if "raymarch_" not in line:
         continue
     m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
     if m and int(m.group(2)) > 1:      # the timed launches, not the single instrumented one
@@ -28,6 +28,9 @@ for line in Path(summary).read_text().splitlines():
 traffic = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
 out = Path(__file__).resolve().parent.parent / "profiles" / "traffic.json"
 d = json.loads(out.read_text()) if out.exists() else {}
-d[key] = traffic
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import kernel_source_hash   # the figure is only valid for the kernels it was measured on
+
+d[key] = {"bytes": traffic, "kernel_source_hash": kernel_source_hash(), "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"]}
 out.write_text(json.dumps(d, indent=1) + "\n")
 print(key, traffic, vals)

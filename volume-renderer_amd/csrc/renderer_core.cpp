@@ -150,12 +150,13 @@ bool RendererCore::loadShader(std::string fn, bool reload)
     const size_t idx = fn.find_last_of('/');
     loaded_shader = idx == std::string::npos ? fn : fn.substr(idx + 1);
     cs_program_ = true;
-    if (quirks & kQuirkTruncGrid) {
-        workgroups_x = window_size[0] / kLocalSize;   // src/RendererCore.cpp:121-122
-        workgroups_y = window_size[1] / kLocalSize;
-    } else {
-        workgroups_x = (window_size[0] + kLocalSize - 1) / kLocalSize;
-        workgroups_y = (window_size[1] + kLocalSize - 1) / kLocalSize;
+    updateWorkgroups();
+    // the reference compiles + links the shader here (:112-118); the HIP code objects are loaded now
+    // instead of by the first render() (a cold first launch costs ~16 ms)
+    if (device_ >= 0) {
+        requireDevice("loadShader");
+        check(launch_warm_modules(stream()), "module pre-load");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
     }
     u_.alpha_scale = alpha_scale;
     if (!loaded_dataset.empty()) {
@@ -165,6 +166,24 @@ bool RendererCore::loadShader(std::string fn, bool reload)
     }
     setMessage("Shader Loaded!", "Shader Loaded Successfully!");
     return true;
+}
+
+void RendererCore::updateWorkgroups()
+{
+    if (quirks & kQuirkTruncGrid) {
+        workgroups_x = window_size[0] / kLocalSize;   // src/RendererCore.cpp:121-122
+        workgroups_y = window_size[1] / kLocalSize;
+    } else {
+        workgroups_x = (window_size[0] + kLocalSize - 1) / kLocalSize;
+        workgroups_y = (window_size[1] + kLocalSize - 1) / kLocalSize;
+    }
+}
+
+void RendererCore::setQuirks(uint32_t q)
+{
+    quirks = q;
+    setMinVal(); setMaxVal();                 // Q10 changes what the kernel sees as the window
+    if (cs_program_) updateWorkgroups();      // Q1 changes the dispatch grid; nothing else is touched
 }
 
 // ---------------------------------------------------------------- volume
@@ -182,6 +201,7 @@ size_t RendererCore::storageVoxels(int nx, int ny, int nz, int lay) const
 void RendererCore::freeVolume()
 {
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
+    res_dims_[0] = res_dims_[1] = res_dims_[2] = 0; res_bytes_ = 0;
     if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
     vol12_failed_ = false;
@@ -204,6 +224,9 @@ void RendererCore::setVolume(const void *host, int nx, int ny, int nz, int bytes
     if (!host || nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2))
         throw std::invalid_argument("setVolume: bad dimensions or datasize_bytes");
     requireDevice("setVolume");
+    // nx*ny*nz*bytes must not wrap (three ints of up to 2^31 each): bound it at 2^48 bytes by division
+    if ((uint64_t)nx > (1ull << 48) / (uint64_t)ny / (uint64_t)nz / (uint64_t)bytes)
+        throw std::invalid_argument("setVolume: volume too large");
     const size_t lin_bytes = (size_t)nx * (size_t)ny * (size_t)nz * (size_t)bytes;
     const uint32_t bnx = bricksX(nx), bny = bricksY(ny);
     if (layout == 0) {
@@ -222,6 +245,7 @@ void RendererCore::setVolume(const void *host, int nx, int ny, int nz, int bytes
         check(e, "volume relayout");
     }
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    res_dims_[0] = nx; res_dims_[1] = ny; res_dims_[2] = nz; res_bytes_ = bytes;   // what is resident now
     tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
     voxel_size[0] = sx; voxel_size[1] = sy; voxel_size[2] = sz;
     datasize_bytes = bytes;
@@ -233,12 +257,15 @@ void RendererCore::generateSynthetic(int kind, int nx, int ny, int nz, int bytes
     if (nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2) || (kind != 0 && kind != 1) ||
         (kind == 0 && bytes != 1))
         throw std::invalid_argument("generateSynthetic: bad arguments");
+    if ((uint64_t)nx > (1ull << 48) / (uint64_t)ny / (uint64_t)nz / (uint64_t)bytes)
+        throw std::invalid_argument("generateSynthetic: volume too large");
     requireDevice("generateSynthetic");
     allocVolume(nx, ny, nz, bytes, layout);
     check(launch_gen_volume(d_vol_, bytes, kind, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, param, layout,
                             bricksX(nx), bricksY(ny), stream()),
           "gen_volume_kernel");
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    res_dims_[0] = nx; res_dims_[1] = ny; res_dims_[2] = nz; res_bytes_ = bytes;   // what is resident now
     tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
     voxel_size[0] = voxel_size[1] = voxel_size[2] = 1.0f;
     datasize_bytes = bytes;
@@ -249,7 +276,7 @@ void RendererCore::readVolume(void *host, size_t bytes)
 {
     requireDevice("readVolume");
     if (!d_vol_) throw std::runtime_error("readVolume: no dataset loaded");
-    const size_t lin_bytes = (size_t)tex3D_dim[0] * tex3D_dim[1] * tex3D_dim[2] * (size_t)datasize_bytes;
+    const size_t lin_bytes = (size_t)res_dims_[0] * res_dims_[1] * res_dims_[2] * (size_t)res_bytes_;
     if (!host || bytes < lin_bytes) throw std::invalid_argument("readVolume: buffer too small");
     if (vol_layout_ == 0) {
         check(hipMemcpyAsync(host, d_vol_, lin_bytes, hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H volume)");
@@ -258,9 +285,9 @@ void RendererCore::readVolume(void *host, size_t bytes)
     }
     void *staging = nullptr;
     check(hipMalloc(&staging, lin_bytes), "hipMalloc(staging)");
-    hipError_t e = launch_relayout(d_vol_, staging, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1],
-                                   (uint32_t)tex3D_dim[2], bricksX(tex3D_dim[0]),
-                                   bricksY(tex3D_dim[1]), 1, stream());
+    hipError_t e = launch_relayout(d_vol_, staging, res_bytes_, (uint32_t)res_dims_[0], (uint32_t)res_dims_[1],
+                                   (uint32_t)res_dims_[2], bricksX(res_dims_[0]),
+                                   bricksY(res_dims_[1]), 1, stream());
     if (e == hipSuccess) e = hipMemcpyAsync(host, staging, lin_bytes, hipMemcpyDeviceToHost, stream());
     if (e == hipSuccess) e = hipStreamSynchronize(stream());
     (void)hipFree(staging);
@@ -273,11 +300,15 @@ void RendererCore::setLayout(int lay)
     layout = lay;
     if (!d_vol_ || vol_layout_ == lay) return;
     requireDevice("setLayout");
-    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    const int nx = res_dims_[0], ny = res_dims_[1], nz = res_dims_[2], bytes = res_bytes_;
+    const int old_layout = vol_layout_;
+    const size_t old_alloc = vol_alloc_bytes_;
     void *old = d_vol_;
     d_vol_ = nullptr;
-    try { allocVolume(nx, ny, nz, datasize_bytes, lay); } catch (...) { d_vol_ = old; throw; }
-    hipError_t e = launch_relayout(old, d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz,
+    auto keep = [&]() { res_dims_[0] = nx; res_dims_[1] = ny; res_dims_[2] = nz; res_bytes_ = bytes; };   // allocVolume drops the resident state
+    try { allocVolume(nx, ny, nz, bytes, lay); } catch (...) { d_vol_ = old; vol_layout_ = old_layout; vol_alloc_bytes_ = old_alloc; keep(); throw; }
+    keep();
+    hipError_t e = launch_relayout(old, d_vol_, bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz,
                                    bricksX(nx), bricksY(ny), lay == 0 ? 1 : 0, stream());
     if (e == hipSuccess) e = hipStreamSynchronize(stream());
     (void)hipFree(old);
@@ -290,8 +321,8 @@ void RendererCore::scanDatasetRange()
     // scratch: [0..1] reference-style min/max (index 8390640 skipped), [2..3] exact min/max
     const unsigned init[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
     check(hipMemcpyAsync(d_scratch_, init, sizeof(init), hipMemcpyHostToDevice, stream()), "hipMemcpy(scratch)");
-    check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
-                       vol_layout_, bricksX(tex3D_dim[0]), bricksY(tex3D_dim[1]), 0, 1.0f,
+    check(launch_stats(d_vol_, res_bytes_, (uint32_t)res_dims_[0], (uint32_t)res_dims_[1], (uint32_t)res_dims_[2],
+                       vol_layout_, bricksX(res_dims_[0]), bricksY(res_dims_[1]), 0, 1.0f,
                        d_scratch_, d_scratch_ + 4, stream()),
           "stats_kernel");
     unsigned mm[4];
@@ -299,7 +330,7 @@ void RendererCore::scanDatasetRange()
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
     exact_min_ = (int)mm[2];
     exact_max_ = (int)mm[3];
-    if (datasize_bytes == 2) {
+    if (res_bytes_ == 2) {
         // reference initial values: max_value = -1, min_value = 9000000
         const int mx = mm[1] == 0u && mm[0] == 0xffffffffu ? -1 : (int)mm[1];
         const int mn = mm[0] == 0xffffffffu ? 9000000 : (int)mm[0];
@@ -316,8 +347,8 @@ void RendererCore::computeHistogram(float out[256])
     requireDevice("histogram");
     if (!d_vol_) throw std::runtime_error("histogram: no dataset loaded");
     check(hipMemsetAsync(d_scratch_, 0, sizeof(unsigned) * 264, stream()), "hipMemset(scratch)");
-    check(launch_stats(d_vol_, datasize_bytes, (uint32_t)tex3D_dim[0], (uint32_t)tex3D_dim[1], (uint32_t)tex3D_dim[2],
-                       vol_layout_, bricksX(tex3D_dim[0]), bricksY(tex3D_dim[1]), 1,
+    check(launch_stats(d_vol_, res_bytes_, (uint32_t)res_dims_[0], (uint32_t)res_dims_[1], (uint32_t)res_dims_[2],
+                       vol_layout_, bricksX(res_dims_[0]), bricksY(res_dims_[1]), 1,
                        (float)max_dataset_val, d_scratch_, d_scratch_ + 4, stream()),
           "stats_kernel");
     unsigned counts[256];
@@ -325,7 +356,7 @@ void RendererCore::computeHistogram(float out[256])
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
     // src/RendererCore.cpp:361,400-405: the normaliser starts from the dataset max
     // (16-bit) or -1 (8-bit) and is raised to the largest bin count
-    double max_value = datasize_bytes == 2 ? (double)max_dataset_val : -1.0;
+    double max_value = res_bytes_ == 2 ? (double)max_dataset_val : -1.0;
     for (int i = 1; i < 256; i++) max_value = std::max(max_value, (double)counts[i]);
     for (int i = 0; i < 256; i++) {
         histogram[i] = i == 0 ? 0.0f : (float)counts[i] * 100.0f / (float)max_value;
@@ -337,7 +368,7 @@ double RendererCore::measureStreamRead(int reps)
 {
     requireDevice("measureStreamRead");
     if (!d_vol_) throw std::runtime_error("measureStreamRead: no dataset loaded");
-    const uint64_t bytes = (uint64_t)storageVoxels(tex3D_dim[0], tex3D_dim[1], tex3D_dim[2], vol_layout_) * (uint64_t)datasize_bytes & ~15ull;
+    const uint64_t bytes = (uint64_t)storageVoxels(res_dims_[0], res_dims_[1], res_dims_[2], vol_layout_) * (uint64_t)res_bytes_ & ~15ull;
     hipEvent_t a = nullptr, b = nullptr;
     check(hipEventCreate(&a), "hipEventCreate");
     check(hipEventCreate(&b), "hipEventCreate");
@@ -525,7 +556,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     P.stripe_count = stripe_count_;
     P.fb_compact = fb_compact_ ? 1 : 0;
     P.fb_format = (fb_format_ == 1 && ext_fb_) ? 1 : 0;
-    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    const int nx = res_dims_[0], ny = res_dims_[1], nz = res_dims_[2];
     P.nx = nx; P.ny = ny; P.nz = nz;
     P.fdim[0] = (float)nx; P.fdim[1] = (float)ny; P.fdim[2] = (float)nz;
     P.bnx = (int)bricksX(nx); P.bny = (int)bricksY(ny); P.bnz = (int)bricksZ(nz);
@@ -562,7 +593,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     P.tf_len = tf_lut_.empty() ? 0 : 256;
     P.skip_empty = skip_empty;
 
-    L.bytes_per_voxel = datasize_bytes;
+    L.bytes_per_voxel = res_bytes_;
     L.filter = filter;
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
@@ -579,7 +610,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         bool small = storage < (1ull << 32) && (uint64_t)nx < lim24 && (uint64_t)ny < lim24 && (uint64_t)nz < lim24;
         if (vol_layout_ == 0) small = small && (uint64_t)ny * (uint64_t)nz < lim24;
         else small = small && bsy < lim24 && bsz < lim24;
-        const uint64_t bytes = storage * (uint64_t)datasize_bytes;
+        const uint64_t bytes = storage * (uint64_t)res_bytes_;
         if (bytes >= (1ull << 32)) small = false;
         L.big_offsets = small ? 0 : 1;
         L.vol_bytes32 = small ? (uint32_t)bytes : 0u;
@@ -605,7 +636,9 @@ void RendererCore::setFramebufferFormat(int fmt)
     fb_format_ = fmt;
 }
 
-void RendererCore::launch(uint32_t *spp)
+// everything a launch needs that may touch the host or synchronise (certification, skip grid,
+// tile order, packed copy): done BEFORE the timed region of render()
+float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
 {
     requireDevice("render");
     if (!cs_program_) throw std::runtime_error("render: no shader loaded (call loadShader first)");
@@ -614,14 +647,20 @@ void RendererCore::launch(uint32_t *spp)
     if (!fb) throw std::runtime_error("render: setup() has not allocated the framebuffer");
     if (fb_format_ == 1 && ext_fb_ && !tf_lut_.empty())
         throw std::invalid_argument("render: the (grey, alpha) target format needs a grey mode (no transfer function)");
-    FrameParams P;
-    LaunchConfig L;
     buildFrame(P, L);
     refreshSkipGrid(P, L);
     refreshTileSchedule(P, L);
     refreshPacked12(P, L);
     // the specialised kernels gather from the packed copy when their address tables fit (vr_kernels.hip: dispatch_fast3)
     last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
+    return fb;
+}
+
+void RendererCore::launch(uint32_t *spp)
+{
+    FrameParams P;
+    LaunchConfig L;
+    float4 *fb = prepareLaunch(P, L);
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
 }
 
@@ -634,9 +673,9 @@ void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
 {
     L.packed12 = nullptr;
     L.packed12_bytes = 0;
-    if (!pack12 || datasize_bytes != 2 || vol_layout_ != 1 || L.big_offsets || exact_max_ > 4095) return;
+    if (!pack12 || res_bytes_ != 2 || vol_layout_ != 1 || L.big_offsets || exact_max_ > 4095) return;
     if (!fast_path_eligible(P, L)) return;
-    const size_t voxels = storageVoxels(tex3D_dim[0], tex3D_dim[1], tex3D_dim[2], 1);
+    const size_t voxels = storageVoxels(res_dims_[0], res_dims_[1], res_dims_[2], 1);
     const size_t bytes = voxels / 2 * 3;
     if (bytes + 16 >= (1ull << 32)) return;
     if (!d_vol12_) {
@@ -669,7 +708,7 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
     L.skip_grid_bytes = 0;
     P.skip_empty = 0;
     if (!skip_empty || !fast_path_eligible(P, L)) return;
-    const int nx = tex3D_dim[0], ny = tex3D_dim[1], nz = tex3D_dim[2];
+    const int nx = res_dims_[0], ny = res_dims_[1], nz = res_dims_[2];
     // a batch of 8 samples must stay within +-1 cell of its middle sample: bound the voxel
     // advance per step on every voxel axis (|dir| <= 1)
     float max_delta = 0.0f;
@@ -704,7 +743,7 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
         check(hipMalloc(reinterpret_cast<void **>(&tmp), cells * sizeof(uint16_t)), "hipMalloc(skip grid tmp)");
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_skip_grid_), cells * sizeof(uint16_t));
         if (e == hipSuccess)
-            e = launch_build_skip_grid(d_vol_, datasize_bytes, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, vol_layout_,
+            e = launch_build_skip_grid(d_vol_, res_bytes_, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, vol_layout_,
                                        bricksX(nx), bricksY(ny), tmp, d_skip_grid_, stream());
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         (void)hipFree(tmp);
@@ -766,11 +805,12 @@ void RendererCore::render()
     requireDevice("render");
     // the reference brackets glDispatchCompute with a GL_TIME_ELAPSED query and blocks
     // on its result (src/RendererCore.cpp:149-153); same shape with HIP events
-    FrameParams P;   // certify (may sync) before the timed region
+    // (GL_TIME_ELAPSED covers the dispatch only: all host-side preparation happens first)
+    FrameParams P;
     LaunchConfig L;
-    if (cs_program_ && d_vol_) { buildFrame(P, L); refreshSkipGrid(P, L); refreshTileSchedule(P, L); }
+    float4 *fb = prepareLaunch(P, L);
     check(hipEventRecord(ev0_, stream()), "hipEventRecord");
-    launch(nullptr);
+    check(launch_raymarch(P, L, d_vol_, d_tf_, fb, nullptr, stream(), &last_kernel_), "raymarch launch");
     check(hipEventRecord(ev1_, stream()), "hipEventRecord");
     check(hipEventSynchronize(ev1_), "hipEventSynchronize");
     float ms = 0.0f;
@@ -815,6 +855,8 @@ void RendererCore::readPixels(float *rgba, size_t n_floats)
     requireDevice("readPixels");
     const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1] * 4;
     if (!rgba || n_floats < n) throw std::invalid_argument("readPixels: buffer too small");
+    if (ext_fb_ && (fb_compact_ || fb_format_ == 1))
+        throw std::invalid_argument("readPixels: the external target is compact and/or (grey, alpha): it does not hold fb_w x fb_h RGBA32F pixels");
     const void *src = framebufferDevice();
     if (!src) throw std::runtime_error("readPixels: no framebuffer");
     check(hipMemcpyAsync(rgba, src, n * sizeof(float), hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H framebuffer)");
@@ -826,7 +868,8 @@ void RendererCore::readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes)
     requireDevice("readPixelsRGBA8");
     const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1];
     if (!rgba8 || n_bytes < n * 4) throw std::invalid_argument("readPixelsRGBA8: buffer too small");
-    if (ext_fb_ && fb_format_ == 1) throw std::invalid_argument("readPixelsRGBA8: the (grey, alpha) target has no RGBA form on the device");
+    if (ext_fb_ && (fb_compact_ || fb_format_ == 1))
+        throw std::invalid_argument("readPixelsRGBA8: the external target is compact and/or (grey, alpha): it does not hold fb_w x fb_h RGBA32F pixels");
     const void *src = framebufferDevice();
     if (!src) throw std::runtime_error("readPixelsRGBA8: no framebuffer");
     if (rgba8_capacity_ < n * 4) {

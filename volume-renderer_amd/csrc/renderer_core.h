@@ -72,6 +72,7 @@ public:
     void generateSynthetic(int kind, int nx, int ny, int nz, int bytes, uint32_t param);
     void readVolume(void *host, size_t bytes);
     void setLayout(int layout);
+    void setQuirks(uint32_t q);               // workgroups_x/y + window uniforms only (camera, messages untouched)
     void setTransferFunction(const int32_t *iso, const float *rgba4, int n);
     void getTransferLut(float *lut1024) const;
     void countSamples(uint64_t *total, uint32_t *per_pixel, size_t n_pixels);
@@ -114,6 +115,11 @@ private:
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     void *d_vol_ = nullptr;
     size_t vol_alloc_bytes_ = 0;
+    // geometry and voxel type of the volume that is RESIDENT (set only after a successful upload).
+    // tex3D_dim / datasize_bytes above are GUI inputs of readVolumeData, like the reference's fields;
+    // the reference's shader reads textureSize() of the uploaded texture (VolumeRenderer.cs:62), not them.
+    int res_dims_[3] = {0, 0, 0};
+    int res_bytes_ = 0;
     int vol_layout_ = 0;
     float4 *d_fb_ = nullptr;
     void *ext_fb_ = nullptr;
@@ -156,7 +162,9 @@ private:
     void scanDatasetRange();
     bool certifyDivisor(float b);
     void buildFrame(FrameParams &P, LaunchConfig &L);
+    float4 *prepareLaunch(FrameParams &P, LaunchConfig &L);
     void launch(uint32_t *spp);
+    void updateWorkgroups();
     void setMessage(const std::string &t, const std::string &m) { title = t; msg = m; }
 };
 

@@ -68,9 +68,8 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
     const unsigned tiles_y = (unsigned)((rows + (int)kFastTileH - 1) / (int)kFastTileH);
     // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
     // single tiles win -- balance across the XCDs matters more than sharing brick rows in one
-    // L2 (0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4).  VR_EXP_CHUNK=WxH overrides (experiments).
+    // L2 (0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4).
     unsigned CW = kFastChunkW, CH = kFastChunkH;
-    if (const char *e = std::getenv("VR_EXP_CHUNK")) { unsigned a = 0, b = 0; if (std::sscanf(e, "%ux%u", &a, &b) == 2 && a && b) { CW = a; CH = b; } }
     if (P.stripe_count > 1) CH = 1;          // cyclic stripes: vertically adjacent local tiles are not neighbours
     const unsigned cpr = (tiles_x + CW - 1) / CW, cpc = (tiles_y + CH - 1) / CH, per_chunk = CW * CH;
     struct Chunk { double work; unsigned cx, cy; };

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <fstream>
 #include <sstream>
 
@@ -209,7 +210,13 @@ bool parsePVM(const std::vector<uint8_t> &raw, PvmVolume &out, std::string &err)
     if (!ptr || std::sscanf(ptr, "%d\n", &numc) != 1 || numc < 1) { err = "PVM: bad component count"; return false; }
     ptr = next_line(ptr);
     if (!ptr) { err = "PVM: truncated header"; return false; }
-    const uint64_t payload = (uint64_t)w * (uint64_t)h * (uint64_t)d * (uint64_t)numc;
+    // w*h*d*numc from four untrusted values can wrap 64 bits: bound the running product by the
+    // bytes that are actually there (division, not multiplication)
+    uint64_t payload = 1;
+    for (const uint64_t f : {(uint64_t)w, (uint64_t)h, (uint64_t)d, (uint64_t)numc}) {
+        if (f > (uint64_t)raw.size() / payload) { err = "PVM: payload shorter than header says"; return false; }
+        payload *= f;
+    }
     const uint64_t offset = (uint64_t)(ptr - base);
     if (offset + payload > raw.size()) { err = "PVM: payload shorter than header says"; return false; }
     uint64_t tail = 0;

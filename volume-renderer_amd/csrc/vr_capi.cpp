@@ -303,9 +303,7 @@ int vr_set_accum(vr_handle h, int accum)
 int vr_set_quirks(vr_handle h, uint32_t quirks)
 {
     return guarded(h, [&](vr::RendererCore &c) {
-        c.quirks = quirks;
-        c.setMinVal(); c.setMaxVal();
-        if (!c.loaded_shader.empty()) c.loadShader(c.loaded_shader, false);   // workgroups_x/y follow Q1
+        c.setQuirks(quirks);
     });
 }
 

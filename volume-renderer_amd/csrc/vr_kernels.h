@@ -45,6 +45,9 @@ hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStr
 // RGBA32F -> RGBA8 with glReadPixels' conversion rule
 hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pixels, hipStream_t st);
 
+// one empty launch per translation unit: loads every code object of the library (vr_load_shader)
+hipError_t launch_warm_modules(hipStream_t st);
+
 // streaming 16-byte reads of `bytes` bytes (bandwidth probe)
 hipError_t launch_stream_read(const void *p, uint64_t bytes, unsigned *sink, hipStream_t st);
 

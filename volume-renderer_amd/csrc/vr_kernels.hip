@@ -334,11 +334,7 @@ __device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx
 // bytes more.
 __device__ __forceinline__ uint32_t pair_load_extent(uint32_t vol_bytes)
 {
-#ifdef VR_EXP_NO_PAIR_EXTENT      // experiment: reproduce the bug the regression test pins
-    return vol_bytes;
-#else
     return vol_bytes > 0xfffffffbu ? vol_bytes : vol_bytes + 4u;
-#endif
 }
 
 // ------------------------------------------------------------------ generic kernel
@@ -541,13 +537,7 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // of occupancy per CU, so the headline variant is also built without it).
 // BATCH: samples per gather batch (8: the skip grid's dilation covers exactly that).
 template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH, bool ATAB, bool PK12>
-#ifndef VR_EXP_FAST_OCC          // experiment knobs: waves per SIMD asked of the compiler, batch length
-#define VR_EXP_FAST_OCC 1
-#endif
-#ifndef VR_EXP_FAST_BATCH
-#define VR_EXP_FAST_BATCH 8
-#endif
-__global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(const FrameParams P,
+__global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const float4 *__restrict__ tf,
                                                             const uint32_t vol_bytes,
@@ -566,9 +556,6 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
     __shared__ uint32_t axis_tab[ATAB ? FAST_AXIS_TAB_MAX : 1];
     static_assert(!ATAB || !BIG, "address tables hold 32-bit byte offsets");
-#ifdef VR_EXP_TRACE             // experiment only: per-wave start/end timestamps into spp
-    const unsigned long long trace_t0 = wall_clock64();
-#endif
     unsigned tx, ty;
     if (tile_table) {                                       // host-built longest-first order
         const uint32_t t = tile_table[blockIdx.x];
@@ -578,12 +565,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
         return;                                              // padding block
     }
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#ifdef VR_EXP_ZORDER            // experiment: Morton order of the lanes inside the 8x8 wave tile
-    const unsigned mx = (lane & 1u) | ((lane >> 1) & 2u) | ((lane >> 2) & 4u);
-    const unsigned my = ((lane >> 1) & 1u) | ((lane >> 2) & 2u) | ((lane >> 3) & 4u);
-#else
     const unsigned mx = lane & 7u, my = lane >> 3;
-#endif
     const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + mx);
     const int ly = (int)(ty * FAST_TILE_H + (wave >> 2) * 8u + my);
     int px = lx, py;
@@ -771,24 +753,11 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (ATAB) {
-#if defined(VR_EXP_NOLOAD)
-                    v[u] = (uint32_t)(off[u] & 4095u);
-#else
-#if defined(VR_EXP_MASK)
-                    off[u] &= VR_EXP_MASK;
-#endif
                     v[u] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[u], 0, 0)
                                                : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rs, (int)off[u], 0, 0);
-#endif
                     continue;
                 }
-#if defined(VR_EXP_NOLOAD)      // experiment only: no memory access at all (VALU bound)
-                v[u] = (uint32_t)(off[u] & 4095u);
-#elif defined(VR_EXP_MASK)      // experiment only: fold all accesses into 1 MiB (cache-resident)
-                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u] & (VR_EXP_MASK >> 1));
-#else
                 v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
-#endif
             }
             return false;
         };
@@ -907,17 +876,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
-#ifdef VR_EXP_TRACE
-    if (spp && (threadIdx.x & 63u) == 0) {
-        const unsigned w = blockIdx.x * 8u + (threadIdx.x >> 6);
-        const unsigned long long t1 = wall_clock64();
-        spp[w * 4u + 0] = (uint32_t)trace_t0; spp[w * 4u + 1] = (uint32_t)t1;
-        spp[w * 4u + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-        spp[w * 4u + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
-    }
-#else
     if (spp) spp[pix] = fetches;
-#endif
 }
 
 // ------------------------------------------------------------------ trilinear kernel
@@ -928,10 +887,7 @@ __global__ __launch_bounds__(512, VR_EXP_FAST_OCC) void raymarch_fast_kernel(con
 // Two samples (16 taps) are gathered per batch and software-pipelined.  Grey ramp, composite
 // (MIPM = 0) or MIP (MIPM = 1), iterative accumulation, alpha_scale in [0,1], 32-bit offsets.
 // Every sample goes through the generic kernel's operations in the generic kernel's order.
-#ifndef VR_EXP_TRI_BATCH
-#define VR_EXP_TRI_BATCH 2
-#endif
-constexpr int TRI_BATCH = VR_EXP_TRI_BATCH;
+constexpr int TRI_BATCH = 2;
 
 template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool POW2, int MIPM>
 __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, const VoxelT *__restrict__ vol,
@@ -1159,11 +1115,8 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
 // the shader's order; only WHICH wavefront executes them changes.
 // Same preconditions as the fast kernel's headline shape (NEAREST, grey-ramp composite,
 // iterative accumulation, default view, 32-bit offsets, alpha_scale in [0,1]).
-#ifndef VR_RELAY_WAVES
-#define VR_RELAY_WAVES 4
-#endif
 // measured on cfg3: 2 or 8 wavefronts per tile, batches of 16, 4 tiles per workgroup are all slower
-constexpr int RELAY_WAVES = VR_RELAY_WAVES, RELAY_BATCH = 8;
+constexpr int RELAY_WAVES = 4, RELAY_BATCH = 8;
 // two tiles share one workgroup (and one 32 KiB classification table): 4 workgroups = 8 tiles
 // = 32 wavefronts per CU, the wave-slot limit, instead of 4 tiles per CU
 constexpr int RELAY_TILES = 2, RELAY_THREADS = 64 * RELAY_WAVES * RELAY_TILES;
@@ -1731,22 +1684,6 @@ static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, co
     return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 0>(P, L, vol, tf, fb, spp, rows, st);
 }
 
-#ifdef VR_EXP_HEADLINE_ONLY      // experiment builds only: just the cfg3 headline instance (fast compile)
-template <typename VoxelT, int LAYOUT>
-static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
-                                float4 *fb, uint32_t *spp, int rows, hipStream_t st)
-{
-    if constexpr (sizeof(VoxelT) == 2 && LAYOUT == 1)
-        #ifdef VR_EXP_NOATAB
-        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, false, false>(P, L, vol, tf, fb, spp, rows, st);
-#else
-        if (L.packed12)
-            return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, true, true>(P, L, vol, tf, fb, spp, rows, st);
-        return launch_fast<VoxelT, LAYOUT, DIV_UNIT, 0, false, true, true, true, 0, false, VR_EXP_FAST_BATCH, true, false>(P, L, vol, tf, fb, spp, rows, st);
-#endif
-    return hipErrorInvalidValue;
-}
-#else
 template <typename VoxelT, int LAYOUT>
 static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf,
                                 float4 *fb, uint32_t *spp, int rows, hipStream_t st)
@@ -1761,7 +1698,6 @@ static hipError_t dispatch_fast(const FrameParams &P, const LaunchConfig &L, con
     if (view == 1) return dispatch_fast2<VoxelT, LAYOUT, 1, false>(P, L, vol, tf, fb, spp, rows, st);
     return dispatch_fast2<VoxelT, LAYOUT, 2, false>(P, L, vol, tf, fb, spp, rows, st);
 }
-#endif
 
 // TRILINEAR through the batched kernel (host: tri_path_eligible)
 template <typename VoxelT, int LAYOUT>
@@ -1803,6 +1739,19 @@ static hipError_t raymarch_tu(const FrameParams &P, const LaunchConfig &L, const
     return spp ? launch_generic<T, LAY, true>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st)
                : launch_generic<T, LAY, false>(P, L, vol, tf, fb, spp, tiles_x, tiles_y, st);
 }
+
+// one empty kernel per translation unit: launching it makes the runtime load that unit's code
+// object (vr_load_shader does this up front; a cold first ray-march launch costs ~16 ms otherwise)
+#if VR_TU >= 0
+#define VR_WARM_CAT2(a, b) a##b
+#define VR_WARM_CAT(a, b) VR_WARM_CAT2(a, b)
+__global__ void VR_WARM_CAT(warm_kernel_tu, VR_TU)() {}
+hipError_t VR_WARM_CAT(launch_warm_tu, VR_TU)(hipStream_t st)
+{
+    hipLaunchKernelGGL(VR_WARM_CAT(warm_kernel_tu, VR_TU), dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+#endif
 
 #define VR_TU_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, int rows, int fast, hipStream_t st
 #if VR_TU == 0
@@ -1885,6 +1834,26 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
     default: return raymarch_tu<uint16_t, 1>(P, L, vol, tf, fb, spp, rows, fast, st);
     }
 #endif
+}
+
+__global__ void warm_kernel_main() {}
+#if VR_TU == -1
+hipError_t launch_warm_tu0(hipStream_t st);
+hipError_t launch_warm_tu1(hipStream_t st);
+hipError_t launch_warm_tu2(hipStream_t st);
+hipError_t launch_warm_tu3(hipStream_t st);
+#endif
+hipError_t launch_warm_modules(hipStream_t st)
+{
+    hipLaunchKernelGGL(warm_kernel_main, dim3(1), dim3(64), 0, st);
+    hipError_t e = hipGetLastError();
+#if VR_TU == -1
+    if (e == hipSuccess) e = launch_warm_tu0(st);
+    if (e == hipSuccess) e = launch_warm_tu1(st);
+    if (e == hipSuccess) e = launch_warm_tu2(st);
+    if (e == hipSuccess) e = launch_warm_tu3(st);
+#endif
+    return e;
 }
 
 hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
