@@ -64,12 +64,9 @@ def test_cfg4_tf_skip_fast_equals_generic_and_skip_is_invisible(vra, cfg4):
         assert kernels["fast+skip"] in SPECIALISED and kernels["fast"] in SPECIALISED
         assert kernels["generic"] == "raymarch_generic_kernel"
         assert counts["fast+skip"] == counts["fast"] == counts["generic"]
-        # S of SURVEY section 8 for cfg4 (3.841e9, no early termination at this opacity)
-        assert abs(counts["fast"] / 3.841e9 - 1.0) < 2e-3, counts["fast"]
+        assert 3.0e9 < counts["fast"] < 3.841e9      # the spline's opacity terminates the densest rays early
         assert np.array_equal(bits(frames["fast+skip"]), bits(frames["fast"]))
         assert np.array_equal(bits(frames["fast"]), bits(frames["generic"]))
-        hit = frames["fast"][..., 3] > 0
-        assert abs(hit.mean() - 0.313) < 0.003   # 31.3 % of the pixels hit the box
         assert frames["fast"][..., :3].max() > 0.05   # the transfer function produced a picture
     finally:
         r.setKernelVariant(0); r.setSkipEmpty(False); r.setTransferFunction()
@@ -77,13 +74,23 @@ def test_cfg4_tf_skip_fast_equals_generic_and_skip_is_invisible(vra, cfg4):
 
 def test_cfg4_grey_fast_equals_generic(vra, cfg4):
     r = cfg4
-    r.setKernelVariant(0); r.render()
-    assert r.last_kernel_name in SPECIALISED
-    fast = r.readPixels().copy()
-    r.setKernelVariant(1); r.render()
-    generic = r.readPixels().copy()
-    r.setKernelVariant(0)
-    assert np.array_equal(bits(fast), bits(generic))
+    r.setAlpha(0.0005)                         # deep regime: no ray reaches dest.a >= 0.95
+    try:
+        r.setKernelVariant(0); r.render()
+        assert r.last_kernel_name in SPECIALISED
+        fast = r.readPixels().copy()
+        total, spp = r.countSamples(per_pixel=True)
+        r.setKernelVariant(1); r.render()
+        generic = r.readPixels().copy()
+        assert np.array_equal(bits(fast), bits(generic))
+        # image facts of SURVEY section 8: 31.3 % of the pixels hit the box, rows 274..1885
+        assert abs((spp > 0).mean() - 0.313) < 0.002
+        rows = np.nonzero((spp > 0).any(axis=1))[0]
+        assert (rows[0], rows[-1]) == (274, 1885)
+        # S of SURVEY section 8 for cfg4: 3.841e9 samples without early termination
+        assert abs(total / 3.841e9 - 1.0) < 2e-3, total
+    finally:
+        r.setKernelVariant(0); r.setAlpha(ALPHA)
 
 
 def test_cfg4_sparse_4k_rows_against_oracle(vra, oracle, cfg4, cfg4_host_volume):
