@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-FAST_KERNELS = ("raymarch_fast_kernel", "raymarch_relay_kernel")   # relay = sparse launches of the headline shape
+FAST_KERNELS = ("raymarch_fast_kernel", "raymarch_relay_kernel", "raymarch_slab_kernel")   # relay = sparse launches; slab = LDS-staged bricks
 
 
 def make_renderer(vra, size, **kw):
@@ -886,7 +886,7 @@ def test_relay_kernel_equals_fast_kernel(vra, oracle, variant):
                 for name, block in orbit_blocks(oracle):
                     r.setCameraBlock(block)
                     r.render()
-                    assert r.last_kernel_name == ("raymarch_relay_kernel" if variant == 3 else "raymarch_fast_kernel")
+                    assert r.last_kernel_name == "raymarch_relay_kernel" if variant == 3 else r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_slab_kernel")
                     got = r.readPixels()
                     _, spp = r.countSamples(per_pixel=True)
                     p = oracle.OracleParams(120, 88, cam=block, alpha_scale=alpha, min_val=win[0], max_val=win[1],
@@ -899,12 +899,15 @@ def test_relay_kernel_full_size_shard(vra, cfg3):
     """one rank's stripes of the cfg3 frame at N = 8: relay kernel == fast kernel, bit for bit"""
     r = cfg3
     r.setRowStripes(16, 5, 8)
+    r.setKernelVariant(4)                                   # automatic without the LDS-staged kernel ...
+    r.render()
+    assert r.last_kernel_name == "raymarch_relay_kernel"      # ... still picks the relay for this sparse shard
     r.setKernelVariant(2)
     r.render(); r.kernelMsTake()
     for _ in range(5):
         r.render()
     t_fast = r.kernelMsTake() / 5
-    assert r.last_kernel_name == "raymarch_fast_kernel"
+    assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_slab_kernel")
     fast = r.readPixels()
     r.setKernelVariant(0)
     r.render(); r.kernelMsTake()

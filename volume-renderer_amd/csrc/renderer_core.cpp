@@ -598,6 +598,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
+    L.slab_allowed = force_generic == 4 ? 0 : 1;             // kernel variant 4: automatic, but never the LDS-staged kernel
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
         // VoxelAddr: the strides carry minus the part of the in-brick term the split axis repeats

@@ -76,6 +76,7 @@ struct LaunchConfig {
     uint32_t tile_table_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
+    int slab_allowed;              // the LDS-staged kernel may be used (vr_set_kernel_variant 4 switches it off)
 };
 
 }  // namespace vr

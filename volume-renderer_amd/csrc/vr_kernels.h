@@ -12,6 +12,10 @@ bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L);
 // TRILINEAR in a grey mode with everything the batched trilinear kernel needs except the tile table
 bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L);
 
+// true when (P, L) runs on the LDS-staged kernel (vr_slab.hip): a fast-path configuration on the bricked
+// layout with u8 voxels or the 12-bit packed copy, a classification table, torus tables that fit
+bool slab_path_eligible(const FrameParams &P, const LaunchConfig &L);
+
 // local image rows one launch covers (stripe padding included)
 int launch_local_rows(const FrameParams &P);
 
