@@ -69,7 +69,7 @@ def parse_args():
                     help="N > 1: what the all_gather moves -- RGBA32F, or (grey, alpha) float2 in the grey modes "
                          "(r == g == b there; expanded to RGBA after the gather); auto = ga when the mode is grey")
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
-    ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay)")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay, 3 always relay, 4 LDS-staged slab kernel)")
     ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
     ap.add_argument("--shard", type=int, nargs=2, default=None, metavar=("WORLD", "RANK"),
                     help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")

@@ -1,4 +1,5 @@
-"""The LDS-staged ray-march kernel (vr_slab.hip) against the CPU oracle and against the fast kernel.
+"""The LDS-staged ray-march kernel (vr_slab.hip, opt-in: vr_set_kernel_variant(4)) against the CPU
+oracle and against the fast kernel.
 
 Only WHERE the prefix gathers read from differs (a torus of brick slots in LDS, filled by LDS-DMA,
 instead of scattered global loads); every frame must stay bit-identical and every per-pixel fetch
@@ -66,7 +67,7 @@ def test_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing):
             r.setAlpha(alpha)
             for name, block in cameras(oracle, rng):
                 r.setCameraBlock(block)
-                r.setKernelVariant(2)                            # never the relay kernel: slab wherever it is eligible
+                r.setKernelVariant(4)                            # the LDS-staged kernel wherever it is eligible
                 r.render()
                 seen.add(r.last_kernel_name)
                 got = r.readPixels()
@@ -104,7 +105,7 @@ def test_slab_kernel_modes_and_views(vra, oracle, dtype, mode):
             r.setTransferFunction([0, 90, 160, 255], [[0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
             tf_lut = r.getTransferLut()
         r.setInitialCameraRotation(top, bottom)
-        r.setKernelVariant(2)
+        r.setKernelVariant(4)
         for name, block in cameras(oracle, rng, n_random=2):
             r.setCameraBlock(block)
             r.render()
@@ -137,10 +138,10 @@ def test_slab_equals_fast_kernel_on_shards_and_quirks(vra):
                 elif shard == "stripes":
                     r.setRowStripes(8, 1, 3)
                 frames = {}
-                for variant in (2, 4):
+                for variant in (4, 2):
                     r.setKernelVariant(variant)
                     r.setup((250, 170))                          # fresh (zeroed) target: untouched pixels must agree too
                     r.render()
                     frames[variant] = (r.last_kernel_name, r.readPixels().copy())
-                assert frames[2][0] == SLAB and frames[4][0] == "raymarch_fast_kernel", (quirks, shard, frames[2][0], frames[4][0])
+                assert frames[4][0] == SLAB and frames[2][0] == "raymarch_fast_kernel", (quirks, shard, frames[2][0], frames[4][0])
                 assert np.array_equal(bits(frames[2][1]), bits(frames[4][1])), (quirks, shard)

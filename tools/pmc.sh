@@ -16,4 +16,4 @@ for G in "${CGRP[@]}"; do
   timeout -k 5 150 rocprofv3 --pmc $G --kernel-trace --output-format csv -d "$OUT/pmc_g$i" -o run -- $CMD > "$OUT/g$i.log" 2>&1
 done
 cd "$REPO"
-python tools/summarize_profile.py "$OUT" "$TAG" 2>&1 | grep -E "raymarch_fast" | grep -v "true>" | sed 's/void vr::raymarch_fast_kernel//' | cut -c1-160
+python tools/summarize_profile.py "$OUT" "$TAG" 2>&1 | grep -E "raymarch_" | sed "s/void vr:://" | cut -c1-200

@@ -598,7 +598,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    L.slab_allowed = force_generic == 4 ? 0 : 1;             // kernel variant 4: automatic, but never the LDS-staged kernel
+    L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
         // VoxelAddr: the strides carry minus the part of the in-brick term the split axis repeats
@@ -797,7 +797,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // kernels with address tables + packed copy): fast / relay = 0.30 / 0.36 ms at N = 2 (685
     // active tiles), 0.19 / 0.20 at N = 4 (342), 0.17 / 0.11 at N = 8 (171), 0.51 / 0.67 full frame
     L.sparse_shard = (tile_active_ < 256u) ? 1 : 0;
-    if (force_generic == 2) L.sparse_shard = 0;          // kernel variant 2: never the relay kernel
+    if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
 }
 

@@ -76,7 +76,7 @@ struct LaunchConfig {
     uint32_t tile_table_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
-    int slab_allowed;              // the LDS-staged kernel may be used (vr_set_kernel_variant 4 switches it off)
+    int slab_allowed;              // use the LDS-staged kernel where eligible (vr_set_kernel_variant 4; off by default)
 };
 
 }  // namespace vr

@@ -71,23 +71,40 @@ __device__ __forceinline__ void slab_wait_pieces(int n)
     }
 }
 
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ int uniform_i(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+// wavefront-wide min / max of a float (result uniform): four DPP steps inside each row of 16 lanes, then
+// the four rows through readlane -- 11 instructions, no LDS crossbar
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
 __device__ __forceinline__ float wave_min_f(float v)
 {
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = fminf(v, dpp_f<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f<0x141>(v));     // row_half_mirror
+    v = fminf(v, dpp_f<0x140>(v));     // row_mirror
+    return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 __device__ __forceinline__ float wave_max_f(float v)
 {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
-__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-__device__ __forceinline__ int uniform_i(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
 template <typename T> __device__ __forceinline__ T sel3(int ax, T v0, T v1, T v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
 constexpr int SLAB_NW = 8, SLAB_THREADS = 64 * SLAB_NW;   // one 32x16-pixel tile per workgroup, like the fast kernel
 constexpr int SLAB_PHASE = 4;          // samples per phase (one brick layer at one voxel per step)
-constexpr int SLAB_EPOCH = 16;         // phases per load plan / between two anchors
+#if defined(VR_EXPERIMENTS) && defined(VR_X_EPOCH)
+constexpr int SLAB_EPOCH = VR_X_EPOCH;
+#else
+constexpr int SLAB_EPOCH = 32;         // phases per load plan / between two anchors
+#endif
 constexpr int SLAB_LA = 3;             // phases of prefetch distance asked for (the ring depth may allow less)
 constexpr int SLAB_LDS_BYTES = 80 * 1024 - 512;           // two workgroups per CU (160 KiB)
 constexpr float SLAB_MARGIN = 0.0625f; // voxels: covers the rounding of the iterated positions over an epoch (< 2^-7 voxel for N <= 4096)
@@ -99,10 +116,12 @@ struct SlabCfg {
     static constexpr int SLOT = PK12 ? 96 : 64 * (int)sizeof(VoxelT);   // bytes per brick slot
     static constexpr int CH = SLOT / 16;                                 // 16-byte chunks per slot
     static constexpr int LUT_ENTRIES = sizeof(VoxelT) == 1 ? 256 : 4096;
-    // grey modes: u8 -> (c, a) pairs; 12-bit -> v only (c = v*a, a = v*alpha_scale are the shader's own
-    // two multiplies, done per sample: halves the table so that two workgroups fit a CU);
+    // grey modes: u8 -> 256 (c, a) pairs; 12-bit -> NO table: the window map is computed per sample with the
+    // shader's own operations (certified quotient: 6 VALU instead of one more LDS round trip) and the
+    // 32 KiB it would take go to the ring, which is what decides how far ahead the loads can run;
     // transfer function: 256 RGBA entries + one index byte per window value
-    static constexpr int LUT_BYTES = MODE >= 2 ? 4096 + LUT_ENTRIES : LUT_ENTRIES * (sizeof(VoxelT) == 1 ? 8 : 4);
+    static constexpr bool HAS_LUT = MODE >= 2 || sizeof(VoxelT) == 1;
+    static constexpr int LUT_BYTES = MODE >= 2 ? 4096 + LUT_ENTRIES : (sizeof(VoxelT) == 1 ? LUT_ENTRIES * 8 : 16);
     static constexpr int TAB_ENTRIES = sizeof(VoxelT) == 1 ? 6144 : 3072;   // nx + ny + nz
     static constexpr int MISC_BYTES = 1024;
     static constexpr int RING_RAW = SLAB_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES;
@@ -130,6 +149,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     __shared__ __attribute__((aligned(16))) uint4 plan[SLAB_EPOCH];
     __shared__ float red[SLAB_NW][8];
     __shared__ int geo[8];
+    static_assert(SLAB_EPOCH <= 64 && sizeof(plan) + sizeof(red) + sizeof(geo) <= C::MISC_BYTES, "LDS budget");
 
     const uint32_t t = tile_table[blockIdx.x];
     if (t == 0xffffffffu) return;                                       // padding block
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         return;
     }
     // ---- classification table, with the shader's own operations (see raymarch_fast_kernel)
-    {
+    if (C::HAS_LUT) {
         const int n = P.max_val - P.min_val + 1;
         for (int e = (int)threadIdx.x; e < n; e += SLAB_THREADS) {
             const float s = (float)(P.min_val + e);
@@ -171,11 +191,9 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                 int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
                 idx = clampi(idx, 0, P.tf_len - 1);
                 reinterpret_cast<uint8_t *>(lut)[4096 + e] = (uint8_t)idx;
-            } else if (sizeof(VoxelT) == 1) {
+            } else {
                 const float a = v * P.alpha_scale;
                 lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
-            } else {
-                lut[e] = v;
             }
         }
         if (MODE >= 2) {
@@ -366,20 +384,28 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             qx += dsx; qy += dsy; qz += dsz;
         }
     };
-    // staged: from the torus (two byte reads for the 12-bit stream: a 2-byte LDS read at an odd address is
-    // replayed for ~64 cycles on gfx950, tools/ubench/lds_slab.hip); raw = false: v holds the 16 stream bits
-    auto gather_lds = [&](uint32_t (&v)[BATCH], uint32_t &nib) {
+    // staged gathers come in two halves.  prepare(): positions of the phase's BATCH samples -> LDS offsets
+    // through the torus tables (tables and positions do not depend on what the DMA is doing, so this runs
+    // BEFORE the phase's barrier, overlapped with the other wavefronts).  fetch(): the ring reads proper, after
+    // the barrier (two byte reads for the 12-bit stream: a 2-byte LDS read at an odd address is replayed for
+    // ~64 cycles on gfx950, tools/ubench/lds_slab.hip); v then holds the 16 stream bits around the voxel
+    auto prepare = [&](uint32_t (&off)[BATCH], uint32_t &nib) {
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
             int vi, vj, vk;
             advance_index(vi, vj, vk);
-            const uint32_t off = (uint32_t)tab_x[vi] + (uint32_t)tab_y[vj] + (uint32_t)tab_z[vk];
-            if (PK12) {
-                v[u] = (uint32_t)ring[off] | ((uint32_t)ring[off + 1] << 8);
-                nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);
-            } else {
-                v[u] = (uint32_t)ring[off];
-            }
+            off[u] = (uint32_t)tab_x[vi] + (uint32_t)tab_y[vj] + (uint32_t)tab_z[vk];
+            if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);
+        }
+    };
+    auto fetch = [&](const uint32_t (&off)[BATCH], uint32_t (&v)[BATCH]) {
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+#if defined(VR_EXPERIMENTS) && defined(VR_X_NOGATHER)
+            v[u] = off[u] & 0xfffu; continue;
+#endif
+            if (PK12) v[u] = (uint32_t)ring[off[u]] | ((uint32_t)ring[off[u] + 1] << 8);
+            else v[u] = (uint32_t)ring[off[u]];
         }
     };
     // not staged (an epoch whose footprint does not fit LDS): plain global loads of the voxels
@@ -400,12 +426,13 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[4096u + e];
             const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
             c = q.x; cg = q.y; cb = q.z; a = q.w;
-        } else if (sizeof(VoxelT) == 1) {
+        } else if (C::HAS_LUT) {
             const float2 ca = reinterpret_cast<const float2 *>(lut)[e];
             c = ca.x; a = ca.y;
         } else {
-            const float v = lut[e];
-            a = v * P.alpha_scale;                                       // VolumeRenderer.cs:130 / :164
+            // clamp(float(texel), min, max) == float(clamp(texel, min, max)): the conversion is exact and monotone
+            const float v = div_cert((float)tt - P.fmin, P.fden, P.rden);   // VolumeRenderer.cs:122-124
+            a = v * P.alpha_scale;                                       // :130 / :164
             c = v * a;                                                   // :131
         }
     };
@@ -448,13 +475,24 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         return da >= 0.95f;
     };
 
-    // ---- the phase loop
+    // ---- the phase loop: ONE barrier per phase (it orders "every wavefront has finished reading the layers
+    // of phase p-1" before their slots are overwritten, and "the pieces each wavefront waited for have landed"
+    // before anybody reads them); every 8th phase the barrier doubles as the vote "all rays finished" (a ray
+    // ends early by early ray termination only; the longest prefix, nbmax phases, bounds the loop anyway)
     bool done = false;
     bool fin = nb == 0;
     int b = 0;                                   // phases this ray has marched (== the phase counter while it is live)
     bool epoch_staged = false;
-    for (int p = 0;; p++) {
-        if (__syncthreads_and(fin ? 1 : 0)) break;
+    uint32_t off[BATCH] = {};                    // prepared LDS offsets of the next phase's samples
+    uint32_t nib = 0;
+    bool prepared = false;
+    uint4 entry_next = make_uint4(0u, 0u, 0u, 0u);   // the next phase's plan entry, read before the barrier
+#ifdef VR_EXPERIMENTS
+    unsigned st_epochs = 0, st_cold = 0, st_fallback = 0;
+#endif
+    for (int p = 0; p < nbmax; p++) {
+        if ((p & 7) == 0) { if (__syncthreads_and(fin ? 1 : 0)) break; }
+        else __syncthreads();
         const int pe = p & (SLAB_EPOCH - 1);
         if (pe == 0) {
             // ---- anchor: exact positions of the live rays, min/max over the workgroup
@@ -485,7 +523,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                     const float dlo = sel3(ma, dmn0, dmn1, dmn2), dhi = sel3(ma, dmx0, dmx1, dmx2);
                     const int sg = (dlo > 0.0f && dhi > 0.0f) ? 1 : ((dlo < 0.0f && dhi < 0.0f) ? -1 : 0);
                     const float vslow = fminf(fabsf(dlo), fabsf(dhi)), vfast = fmaxf(fabsf(dlo), fabsf(dhi));
-                    const float horizon = fminf((float)(BATCH * SLAB_EPOCH * 4), (float)steps_left) + (float)(BATCH * SLAB_LA + 8);
+                    const float horizon = fminf((float)(BATCH * SLAB_EPOCH * 2), (float)steps_left) + (float)(BATCH * SLAB_LA + 8);
                     auto span = [&](int x) { return (sel3(x, Amax0, Amax1, Amax2) - sel3(x, Amin0, Amin1, Amin2)) + horizon * (sel3(x, dmx0, dmx1, dmx2) - sel3(x, dmn0, dmn1, dmn2)) + 2.0f * SLAB_MARGIN; };
                     status = 2;
                     if (sg != 0 && vslow >= 0.125f) {
@@ -520,61 +558,99 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             __syncthreads();
             const int status = uniform_i(geo[5]);
             epoch_staged = status != 2;
+#ifdef VR_EXPERIMENTS
+            st_epochs++; st_cold += status == 1; st_fallback += status == 2;
+#endif
             if (status == 1) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // nothing of the old torus may still be landing
                 adopt_geometry();
                 __syncthreads();
             }
+            if (epoch_staged) entry_next = plan[0];
         }
         // ---- loader: request the layers this phase's plan entry names
         int tail_pieces = 0;
         if (epoch_staged) {
-            const uint4 e = plan[pe];
+            const uint4 e = entry_next;
             const int first_b = uniform_i((int)e.x);
             const uint32_t ey = __builtin_amdgcn_readfirstlane(e.y), ez = __builtin_amdgcn_readfirstlane(e.z), ew = __builtin_amdgcn_readfirstlane(e.w);
-            const int lo_a = (int)(ey & 0xffffu), lo_b = (int)(ey >> 16);
-            const int n = (int)(ez & 15u), keep = (int)((ez >> 4) & 15u), dda = (int)((ez >> 8) & 31u), ddb = (int)((ez >> 13) & 31u);
-            const int la = (int)((ez >> 18) & 31u), lb = (int)((ez >> 23) & 31u);
-            int lz = (int)(ew & 0xffu);
-            const bool cold = (ew & 0x100u) != 0u;
-            for (int l = 0; l < n; l++) {
-                const uint32_t layer_idx = (uint32_t)(first_b + sgn * l) * sM;   // uniform
+            const int n = (int)(ez & 15u);
+            if (n > 0) {
+                const int lo_a = (int)(ey & 0xffffu), lo_b = (int)(ey >> 16);
+                const int keep = (int)((ez >> 4) & 15u), dda = (int)((ez >> 8) & 31u), ddb = (int)((ez >> 13) & 31u);
+                const int la = (int)((ez >> 18) & 31u), lb = (int)((ez >> 23) & 31u);
+                int lz = (int)(ew & 0xffu);
+                const bool cold = (ew & 0x100u) != 0u;
+                // this lane's brick inside the rectangle, per piece (the same for every layer of the entry)
+                uint32_t rel[SLAB_MAX_PIECES];
+                bool ok[SLAB_MAX_PIECES];
 #pragma unroll
                 for (int q = 0; q < SLAB_MAX_PIECES; q++) {
-                    if (q >= pieces) break;
                     int oa = ld_ta[q] - la, ob = ld_tb[q] - lb;
                     if (oa < 0) oa += RA;
                     if (ob < 0) ob += RB;
-                    const bool ok = ld_ok[q] && oa <= dda && ob <= ddb;
-                    if (__any(ok ? 1 : 0)) {
-                        if (ok) {
-                            const uint32_t idx = __umul24((uint32_t)(lo_a + oa), sA) + __umul24((uint32_t)(lo_b + ob), sB) + layer_idx;
-                            const uint8_t *g = src + (uint64_t)idx * (uint64_t)C::SLOT + (uint64_t)(ld_part[q] * 16);
-                            glds16(g, ring_base + (uint32_t)lz * layer_bytes + (uint32_t)(q * SLAB_NW + (int)wave) * 1024u);
-                        }
-                        if (l >= n - keep) tail_pieces++;
-                    }
+                    ok[q] = ld_ok[q] && oa <= dda && ob <= ddb;
+                    rel[q] = __umul24((uint32_t)(lo_a + oa), sA) + __umul24((uint32_t)(lo_b + ob), sB);
                 }
-                lz += sgn;
-                if (lz >= RZ) lz = 0;
-                if (lz < 0) lz = RZ - 1;
-            }
-            if (cold) {                                                  // first phase on a fresh torus: everything is needed now
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                tail_pieces = 0;
+                for (int l = 0; l < n; l++) {
+                    const uint32_t layer_idx = (uint32_t)(first_b + sgn * l) * sM;   // uniform
+#pragma unroll
+                    for (int q = 0; q < SLAB_MAX_PIECES; q++) {
+                        if (q >= pieces) break;
+                        if (__any(ok[q] ? 1 : 0)) {
+                            if (ok[q]) {
+                                const uint8_t *g = src + (uint64_t)(rel[q] + layer_idx) * (uint64_t)C::SLOT + (uint64_t)(ld_part[q] * 16);
+#if !(defined(VR_EXPERIMENTS) && defined(VR_X_NODMA))
+                                glds16(g, ring_base + (uint32_t)lz * layer_bytes + (uint32_t)(q * SLAB_NW + (int)wave) * 1024u);
+#else
+                                asm volatile("" :: "v"(g));
+#endif
+                            }
+                            if (l >= n - keep) tail_pieces++;
+                        }
+                    }
+                    lz += sgn;
+                    if (lz >= RZ) lz = 0;
+                    if (lz < 0) lz = RZ - 1;
+                }
+                if (cold) {                                              // first phase on a fresh torus: everything is needed now
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    tail_pieces = 0;
+                }
             }
         }
         // ---- this phase's four samples
+        // (the two branches do not share their compositing code on purpose: the compiler waits for the
+        // global loads of the unstaged branch where their results are used, and a wait placed at a common
+        // join would also drain the staged branch's LDS-DMA pieces, which it cannot tell apart)
         if (!fin) {
-            uint32_t v[BATCH];
-            uint32_t nib = 0;
-            if (epoch_staged) gather_lds(v, nib); else gather_global(v);
-            if (consume(v, nib, !epoch_staged)) { done = true; fin = true; }
+            bool term;
+            if (epoch_staged) {
+                uint32_t v[BATCH];
+                if (!prepared) prepare(off, nib);
+                fetch(off, v);
+                term = consume(v, nib, false);
+            } else {
+                uint32_t v[BATCH];
+                gather_global(v);
+                term = consume(v, 0u, true);
+                asm volatile("" ::: "memory");
+            }
+            if (term) { done = true; fin = true; }
             else if (++b >= nb) fin = true;
         }
-        // ---- what the next phase reads must have landed before the barrier at the top
+        // ---- the next phase's table look-ups and plan entry, ahead of its barrier (not across an epoch
+        // boundary: the anchor wants the positions of the phase's first sample, and the plan may change)
+        prepared = false;
+        if (epoch_staged && pe != SLAB_EPOCH - 1) {
+            entry_next = plan[pe + 1];
+            if (!fin) { prepare(off, nib); prepared = true; }
+        }
+        // ---- what the next phase reads must have landed before its barrier
+#if !(defined(VR_EXPERIMENTS) && defined(VR_X_NOWAIT))
         if (epoch_staged) slab_wait_pieces(tail_pieces);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // no DMA may outlive the workgroup's LDS
 
@@ -609,6 +685,9 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
+#ifdef VR_EXPERIMENTS      // per-tile load-plan statistics instead of the fetch count of the tile's first pixel
+    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | st_epochs | (st_cold << 8) | (st_fallback << 16) | ((unsigned)(RA * RB) << 24 & 0x7f000000u); return; }
+#endif
     if (spp) spp[pix] = (uint32_t)i;
 }
 
