@@ -205,6 +205,37 @@ int vr_save_image(vr_handle h, const char *path, const char *ext);
 int vr_write_image_rgb8(const char *path, const char *ext, int width, int height,
                         const unsigned char *rgb, int stride_bytes);
 
+/* ---- one node, several GPUs, one process (shards the single dispatch of
+        src/RendererCore.cpp:149-151 so that a caller shaped like RendererGUI::run,
+        src/RendererGUI.cpp:100-101, uses every GPU by calling vr_group_render where it called
+        render()).  One renderer per device: the volume is replicated (load / generate it on every
+        member), the image rows are sharded, the shards are gathered on devices[0] -- over RCCL
+        (grouped ncclSend/ncclRecv across xGMI, librccl loaded on first use) when the devices are
+        distinct, with peer copies otherwise -- and assembled there into one RGBA32F frame.
+        Members are ordinary handles: configure them with the calls above (the same values on every
+        member); their row range / stripes / target are owned by the group. ------------------------ */
+typedef struct vr_group *vr_group_handle;
+int vr_group_create(vr_group_handle *out, const int *devices, int n);
+void vr_group_destroy(vr_group_handle g);
+int vr_group_size(vr_group_handle g);
+vr_handle vr_group_member(vr_group_handle g, int rank);
+/* vr_setup on every member + the shard plan: partition 0 = cyclic stripes of `stripe_rows` rows
+   (balanced: only ~75 % of the rows hit the box at the default camera), 1 = contiguous row blocks */
+int vr_group_setup(vr_group_handle g, int win_w, int win_h, int fb_w, int fb_h, int partition, int stripe_rows);
+/* 1 (default): RCCL when every member has its own device; 0: always peer copies; 2: like 1, and a
+   one-member group also creates its communicator (a probe that RCCL loads and initialises here).
+   Call before vr_group_setup. */
+int vr_group_set_transport(vr_group_handle g, int use_rccl);
+const char *vr_group_transport(vr_group_handle g);     /* what vr_group_setup chose */
+/* render(): every member's shard kernel (concurrently, one stream per device), the gather and the
+   assembly; blocks until the frame is complete on devices[0].  Adds the slowest member's kernel
+   time to the group's kerneltime_sum. */
+int vr_group_render(vr_group_handle g);
+float vr_group_kernel_ms_take(vr_group_handle g);
+void *vr_group_framebuffer_device(vr_group_handle g);   /* fb_w x fb_h RGBA32F on devices[0] */
+int vr_group_read_pixels(vr_group_handle g, float *rgba, size_t n_floats);
+const char *vr_group_last_error(vr_group_handle g);
+
 /* name of the kernel variant the last vr_render* launched (for profiles/tests) */
 const char *vr_last_kernel_name(vr_handle h);
 

@@ -1,7 +1,9 @@
 /* Plain-C client of include/vr_core.h: proves the header is valid C (no C++/torch types in
  * the ABI) and that libvr_core.so links and runs from C.
  *   client host   -> host-only handle: camera, shader bookkeeping, transfer function, errors
- *   client gpu    -> render config 0 on device 0 and print a checksum of the frame        */
+ *   client gpu    -> render config 0 on device 0 and print a checksum of the frame
+ *   client group N -> the same frame through vr_group_* with N members (all on device 0
+ *                    when the box has fewer than N GPUs)                                   */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,9 +16,35 @@ static int fail(const char *what, vr_handle h)
     return 1;
 }
 
+static int group_mode(int n)
+{
+    int devices[64];
+    vr_group_handle g = NULL;
+    static float frame[256 * 256 * 4];
+    double sum = 0.0;
+    int r, i;
+    if (n < 1 || n > 64) return 1;
+    for (r = 0; r < n; r++) devices[r] = 0;            /* a one-GPU box: every member on device 0 */
+    if (vr_group_create(&g, devices, n) != VR_OK) { fprintf(stderr, "FAIL vr_group_create\n"); return 1; }
+    if (vr_group_setup(g, 256, 256, 256, 256, 0, 16) != VR_OK) { fprintf(stderr, "FAIL vr_group_setup: %s\n", vr_group_last_error(g)); return 1; }
+    for (r = 0; r < vr_group_size(g); r++) {
+        vr_handle h = vr_group_member(g, r);
+        if (vr_load_shader(h, "VolumeRenderer.cs", 0) != VR_OK) return fail("member load_shader", h);
+        if (vr_generate_synthetic(h, VR_SYNTH_SPHERE_U8, 64, 64, 64, 1, 28) != VR_OK) return fail("member generate", h);
+    }
+    if (vr_group_render(g) != VR_OK) { fprintf(stderr, "FAIL vr_group_render: %s\n", vr_group_last_error(g)); return 1; }
+    if (vr_group_read_pixels(g, frame, 256 * 256 * 4) != VR_OK) { fprintf(stderr, "FAIL vr_group_read_pixels: %s\n", vr_group_last_error(g)); return 1; }
+    for (i = 0; i < 256 * 256 * 4; i++) sum += frame[i];
+    printf("group %d transport [%s] ms %.4f sum %.6f centre_alpha %.8f\n", vr_group_size(g), vr_group_transport(g),
+           vr_group_kernel_ms_take(g), sum, frame[(128 * 256 + 128) * 4 + 3]);
+    vr_group_destroy(g);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+    if (argc > 2 && strcmp(argv[1], "group") == 0) return group_mode(atoi(argv[2]));
     vr_handle h = NULL;
     if (vr_create(&h, gpu ? 0 : -1) != VR_OK) return fail("vr_create", NULL);
     if (vr_setup(h, 256, 256, 256, 256) != VR_OK) return fail("vr_setup", h);

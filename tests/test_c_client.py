@@ -38,3 +38,15 @@ def test_c_client_renders_cfg0(vra, tmp_path, oracle):
     assert f"samples {total} " in out and any(k in out for k in ("raymarch_fast_kernel", "raymarch_relay_kernel", "raymarch_slab_kernel"))
     assert f"centre_alpha {want[128, 128, 3]:.8f}" in out
     assert f"sum {float(np.sum(want.astype(np.float64))):.6f}" in out
+
+
+@pytest.mark.gpu
+def test_c_client_group_mode(vra, tmp_path, oracle):
+    """vr_group_* from plain C: 4 members (on one device here), the gathered frame is config 0's frame"""
+    exe = build(tmp_path, vra)
+    out = subprocess.run([str(exe), "group", "4"], check=True, capture_output=True, text=True).stdout
+    vol = oracle.gen_sphere_u8(64, 28)
+    want, _ = oracle.render(vol, oracle.OracleParams(256, 256))
+    assert "group 4 transport [hipMemcpyPeerAsync]" in out
+    assert f"centre_alpha {want[128, 128, 3]:.8f}" in out
+    assert f"sum {float(np.sum(want.astype(np.float64))):.6f}" in out

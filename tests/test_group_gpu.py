@@ -1,0 +1,64 @@
+"""vr_group_*: the native (single-process) multi-GPU path of the C ABI.  A one-GPU box can only
+put several members on the same device -- that exercises the shard plan, the compact (grey, alpha)
+/ RGBA shard targets, the gather buffers and the assembly kernel with the peer-copy transport; the
+RCCL transport is initialised and used for real with a one-member group (ncclCommInitAll over one
+device is legal) and on a multi-GPU node whenever the devices are distinct."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def configure(r, vra, vol, tf):
+    assert r.loadShader("VolumeRenderer.cs")
+    r.setQuirks(0)
+    r.setVolume(vol)
+    r.setWindow(5, 240)
+    r.setAlpha(0.05)
+    r.cameraOrient(0, 0.06 * 5, 0.06 * 11)
+    if tf:
+        r.setTransferFunction([0, 90, 160, 255], [[0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
+
+
+@pytest.mark.parametrize("tf", [False, True], ids=["grey_float2_shards", "tf_rgba_shards"])
+@pytest.mark.parametrize("partition,stripe_rows", [("stripes", 16), ("stripes", 5), ("contiguous", 16)])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_group_frame_equals_single_device_frame(vra, n, partition, stripe_rows, tf):
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 256, size=(48, 40, 56), dtype=np.uint8)
+    size = (203, 157)                                   # neither a multiple of the stripe height nor of n
+    with vra.RendererCore(0) as single:
+        single.setup(size)
+        configure(single, vra, vol, tf)
+        single.render()
+        want = single.readPixels()
+    with vra.RendererGroup([0] * n) as g:
+        g.setup(size, partition=partition, stripe_rows=stripe_rows)
+        g.each(lambda m: configure(m, vra, vol, tf))
+        g.render()
+        got = g.readPixels()
+        assert g.kernelMsTake() > 0.0
+        assert ("peer" in g.transport.lower()) == (n > 1)
+        g.render()                                      # a second frame re-uses every buffer
+        again = g.readPixels()
+    assert np.array_equal(bits(got), bits(want)), (n, partition, stripe_rows, tf)
+    assert np.array_equal(bits(again), bits(want))
+
+
+def test_rccl_loads_and_initialises_on_this_box(vra):
+    """transport mode 2: a one-member group still creates its RCCL communicator (dlopen of librccl.so,
+    ncclCommInitAll over one device) -- what a multi-GPU node does, minus the peers"""
+    with vra.RendererGroup([0]) as g:
+        g.setTransport(2)
+        g.setup((64, 48))
+        assert g.transport.startswith("rccl"), g.transport
+    with vra.RendererGroup([0]) as g:
+        g.setup((64, 48))
+        assert g.transport.startswith("none")           # default: nothing to gather, RCCL stays unloaded
+    with vra.RendererGroup([0, 0]) as g:                # duplicates can never form a communicator: peer copies
+        g.setup((64, 48))
+        assert "peer" in g.transport.lower()

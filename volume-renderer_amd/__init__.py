@@ -11,6 +11,7 @@ module ``volume_renderer_amd``.
 from .renderer import (  # noqa: F401
     LIB_PATH,
     RendererCore,
+    RendererGroup,
     VRError,
     build_library,
     checksum,
@@ -23,6 +24,7 @@ from .renderer import (  # noqa: F401
 __all__ = [
     "LIB_PATH",
     "RendererCore",
+    "RendererGroup",
     "VRError",
     "build_library",
     "checksum",

@@ -79,6 +79,9 @@ public:
     void readPixels(float *rgba, size_t n_floats);
     void *framebufferDevice() const { return ext_fb_ ? ext_fb_ : d_fb_; }
     void setStream(hipStream_t s) { user_stream_ = s; }
+    hipStream_t streamHandle() const { return stream(); }     // the stream the next launch goes to
+    bool greyMode() const { return tf_lut_.empty(); }          // r == g == b in every pixel (no transfer function)
+    void prepareForLaunch() { FrameParams P; LaunchConfig L; (void)prepareLaunch(P, L); }   // certification, tile order, packed copy: host work a timed launch should not carry
     void setExternalFramebuffer(void *p) { ext_fb_ = p; }
     void setRowRange(int b, int e) { row_begin_ = b; row_end_ = e; }
     void setRowStripes(int rows, int index, int count);

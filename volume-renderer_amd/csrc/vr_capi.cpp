@@ -9,12 +9,9 @@
 
 #include "../../include/vr_core.h"
 #include "renderer_core.h"
+#include "vr_handle.h"
 #include "volume_io.h"
 
-struct vr_renderer {
-    vr::RendererCore core;
-    explicit vr_renderer(int device) : core(device) {}
-};
 
 namespace {
 

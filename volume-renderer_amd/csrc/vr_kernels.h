@@ -52,6 +52,12 @@ hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pix
 // one empty launch per translation unit: loads every code object of the library (vr_load_shader)
 hipError_t launch_warm_modules(hipStream_t st);
 
+// multi-GPU assembly on the root device (vr_group.cpp): gathered = n rank-major compact shards of local_rows x W
+// pixels with `channels` floats each (2 = (grey, alpha), 4 = RGBA); stripe_rows = 0: contiguous row blocks,
+// else cyclic stripes of that many rows; frame = W x H RGBA32F
+hipError_t launch_assemble(const void *gathered, float4 *frame, int W, int H, int n, int local_rows, int stripe_rows,
+                           int channels, hipStream_t st);
+
 // streaming 16-byte reads of `bytes` bytes (bandwidth probe)
 hipError_t launch_stream_read(const void *p, uint64_t bytes, unsigned *sink, hipStream_t st);
 

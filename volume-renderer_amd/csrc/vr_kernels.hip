@@ -1656,6 +1656,29 @@ hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pix
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void assemble_kernel(const float *__restrict__ gathered, float4 *__restrict__ frame, int W, int H,
+                                                       int n, int local_rows, int stripe_rows, int channels)
+{
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x), gy = (int)blockIdx.y;
+    if (x >= W || gy >= H) return;
+    int k, lr;
+    if (stripe_rows == 0) { k = gy / local_rows; lr = gy % local_rows; }
+    else { const int s = gy / stripe_rows; k = s % n; lr = (s / n) * stripe_rows + gy % stripe_rows; }
+    const size_t src = ((size_t)k * (size_t)local_rows + (size_t)lr) * (size_t)W + (size_t)x;
+    float4 px;
+    if (channels == 2) { const float2 ga = reinterpret_cast<const float2 *>(gathered)[src]; px = make_float4(ga.x, ga.x, ga.x, ga.y); }
+    else px = reinterpret_cast<const float4 *>(gathered)[src];
+    frame[(size_t)gy * (size_t)W + (size_t)x] = px;
+}
+
+hipError_t launch_assemble(const void *gathered, float4 *frame, int W, int H, int n, int local_rows, int stripe_rows,
+                           int channels, hipStream_t st)
+{
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, st, (const float *)gathered, frame, W, H,
+                       n, local_rows, stripe_rows, channels);
+    return hipGetLastError();
+}
+
 // streaming read of a device buffer with 16-byte loads: the box's achievable HBM read rate,
 // measured next to the ray-march (vr_measure_stream_read)
 __global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16, unsigned *sink)

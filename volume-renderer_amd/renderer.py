@@ -141,6 +141,18 @@ def load_library() -> C.CDLL:
         "vr_checksum": (C.c_uint, [C.c_void_p, C.c_uint]),
         "vr_write_image_rgb8": (i32, [C.c_char_p, C.c_char_p, i32, i32, C.c_void_p, i32]),
         "vr_free": (None, [C.c_void_p]),
+        "vr_group_create": (i32, [C.POINTER(h), C.POINTER(i32), i32]),
+        "vr_group_destroy": (None, [h]),
+        "vr_group_size": (i32, [h]),
+        "vr_group_member": (h, [h, i32]),
+        "vr_group_setup": (i32, [h, i32, i32, i32, i32, i32, i32]),
+        "vr_group_set_transport": (i32, [h, i32]),
+        "vr_group_transport": (C.c_char_p, [h]),
+        "vr_group_render": (i32, [h]),
+        "vr_group_kernel_ms_take": (f32, [h]),
+        "vr_group_framebuffer_device": (C.c_void_p, [h]),
+        "vr_group_read_pixels": (i32, [h, C.POINTER(f32), C.c_size_t]),
+        "vr_group_last_error": (C.c_char_p, [h]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)   # AttributeError = header/library drift: fail loudly
@@ -180,6 +192,80 @@ def _fp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+class RendererGroup:
+    """vr_group_*: one process, one renderer per device, image rows sharded, shards gathered on
+    devices[0] (RCCL over xGMI when the devices are distinct).  Members are RendererCore objects
+    borrowed from the group: configure every member alike (volume, window, camera ...)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._g = C.c_void_p()
+        arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.vr_group_create(C.byref(self._g), arr, len(devices))
+        if rc != VR_OK:
+            raise VRError(rc, "vr_group_create failed")
+        self.members = [RendererCore._borrowed(self._lib, self._lib.vr_group_member(self._g, r), devices[r]) for r in range(len(devices))]
+        self.framebuffer_size = (0, 0)
+
+    def _check(self, rc):
+        if rc != VR_OK:
+            raise VRError(rc, (self._lib.vr_group_last_error(self._g) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m._h = None
+            self._lib.vr_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setup(self, window_size, framebuffer_size=None, partition="stripes", stripe_rows=16):
+        fb = framebuffer_size or window_size
+        self._check(self._lib.vr_group_setup(self._g, window_size[0], window_size[1], fb[0], fb[1], 0 if partition == "stripes" else 1, stripe_rows))
+        self.framebuffer_size = (int(fb[0]), int(fb[1]))
+        for m in self.members:
+            m.framebuffer_size = self.framebuffer_size
+
+    def setTransport(self, mode: int):
+        """0 peer copies, 1 RCCL when the devices are distinct (default), 2 also create the communicator of a one-member group"""
+        self._check(self._lib.vr_group_set_transport(self._g, int(mode)))
+
+    @property
+    def transport(self) -> str:
+        return (self._lib.vr_group_transport(self._g) or b"").decode()
+
+    def each(self, fn):
+        """apply fn(member) to every member (the group keeps them in step only for what it owns: rows, targets)"""
+        for m in self.members:
+            fn(m)
+
+    def render(self):
+        self._check(self._lib.vr_group_render(self._g))
+
+    def kernelMsTake(self) -> float:
+        return float(self._lib.vr_group_kernel_ms_take(self._g))
+
+    def framebufferDevice(self) -> int:
+        return int(self._lib.vr_group_framebuffer_device(self._g) or 0)
+
+    def readPixels(self) -> np.ndarray:
+        w, h = self.framebuffer_size
+        out = np.zeros((h, w, 4), dtype=np.float32)
+        self._check(self._lib.vr_group_read_pixels(self._g, _fp(out), out.size))
+        return out
+
+
 class RendererCore:
     """Host mirror of the reference's RendererCore over the C ABI.
 
@@ -196,6 +282,17 @@ class RendererCore:
         self.device = device
         self.framebuffer_size = (0, 0)
 
+    @classmethod
+    def _borrowed(cls, lib, handle, device):
+        """a RendererCore around a handle somebody else owns (vr_group_member): close() leaves it alone"""
+        self = cls.__new__(cls)
+        self._lib = lib
+        self._h = C.c_void_p(handle)
+        self._owned = False
+        self.device = device
+        self.framebuffer_size = (0, 0)
+        return self
+
     # -- plumbing
     def _check(self, rc: int):
         if rc != VR_OK:
@@ -203,7 +300,8 @@ class RendererCore:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.vr_destroy(self._h)
+            if getattr(self, "_owned", True):
+                self._lib.vr_destroy(self._h)
             self._h = None
 
     def __del__(self):
