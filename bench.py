@@ -79,6 +79,10 @@ def parse_args():
                     help="also time the slow secondary measurements (PCIe read-back, orbiting camera); the secondary "
                          "kernel regimes (unpacked, shallow, off-axis, trilinear) are always in `extras` at N=1")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary kernel regimes")
+    ap.add_argument("--native-group", action="store_true",
+                    help="N > 1 without torch.distributed: ONE process drives --gpus members through the C ABI's vr_group_* "
+                         "(a renderer per device, RCCL send/recv gather to device 0, assembly kernel there); when the box has "
+                         "fewer devices than members, members share devices (validation only)")
     ap.add_argument("--dataset", default=None,
                     help="render a volume file (.raw + .raw.inf, or .pvm) instead of the synthetic volume; --bytes gives its "
                          "voxel size.  VR_DATA_BONSAI / VR_DATA_HEAD name the reference's two datasets (README.md:6-7) for "
@@ -114,8 +118,70 @@ def self_launch(args) -> int:
     return 0
 
 
+def run_native_group(args) -> int:
+    """the headline frame through vr_group_*: one process, one renderer per device, the frame complete on device 0.
+    A step = vr_group_render(): shard kernels on every device concurrently + gather + assembly, blocking (like the
+    reference's render()); wall clock around K steps."""
+    import numpy as np
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+
+    vra = importlib.import_module("volume-renderer_amd")
+    R = vra.renderer
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        print("bench.py needs a HIP device (no CPU fallback exists)", file=sys.stderr)
+        return 1
+    n, W, H, N, b = args.gpus, args.width, args.height, args.volume, args.bytes
+    devices = [r % ndev for r in range(n)]
+    dims = tuple(args.dims) if args.dims else (N, N, N)
+    vmax = 4095 if b == 2 else 255
+    win = tuple(args.window) if args.window else (0, vmax)
+    g = vra.RendererGroup(devices)
+    g.setup((W, H), partition=args.partition, stripe_rows=args.stripe_rows)
+
+    def configure(m):
+        m.loadShader("VolumeRenderer.cs"); m.setQuirks(0)
+        m.setLayout(R.LAYOUT_BRICKED if args.layout == "bricked" else R.LAYOUT_LINEAR)
+        m.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
+        m.setWindow(*win); m.setAlpha(args.alpha); m.setKernelVariant(args.kernel_variant); m.setPack12(not args.no_pack12)
+        m.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
+        if args.pose == "offaxis":
+            m.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+    g.each(configure)
+    for _ in range(max(args.clock_ramp_frames, 0) // 4 + args.warmup):
+        g.render()
+    g.kernelMsTake()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.render()
+    ms_per_step = (time.perf_counter() - t0) * 1e3 / args.steps
+    kernel_ms = g.kernelMsTake() / args.steps
+    frame = g.readPixels()
+    with vra.RendererCore(devices[0]) as single:          # untimed self-check against one device's own full frame
+        single.setup((W, H)); configure(single)
+        single.render()
+        want = single.readPixels()
+        samples = single.countSamples()
+    ok = bool(np.array_equal(frame.view(np.uint32), want.view(np.uint32)))
+    print(json.dumps({
+        "metric": "Msamples/sec (+ Mpixels/sec), 1024^3 uint16 @ 1920x1080", "value": round(samples / (ms_per_step * 1e-3) / 1e6, 1),
+        "unit": "Msamples/s", "mpixels_per_s": round(W * H / (ms_per_step * 1e-3) / 1e6, 1), "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic noise-ball {'x'.join(map(str, dims))} uint{8 * b}, {W}x{H} RGBA32F, {args.filter.upper()} filter, "
+                               f"window [{win[0]},{win[1]}], alpha_scale {args.alpha}, {args.layout} layout",
+                   "samples_per_frame": samples, "launcher": "native vr_group (one process, C ABI)", "devices": devices,
+                   "transport": g.transport, "partition": args.partition, "kernel": g.members[0].last_kernel_name},
+        "multi_gpu_frame_bit_exact": ok, "n_ranks_seen": len(g.members)}), flush=True)
+    g.close()
+    return 0 if ok else 1
+
+
 def main():
     args = parse_args()
+    if args.native_group:
+        raise SystemExit(run_native_group(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))      # before torch / HIP are touched in this process
     import numpy as np

@@ -140,9 +140,13 @@ __device__ __forceinline__ int floor_to_int_sat(float f)
 // X[i] + Y[j] + Z[k] = byte offset of voxel (i,j,k) = sizeof(VoxelT) * VoxelAddr<LAYOUT,false>::at.
 // PK12 (12-bit packed copy): the Y and Z element terms are multiples of BRICK_X (even), so
 // floor(1.5*(x + y + z)) = floor(1.5*x) + 1.5*y + 1.5*z.  Called by all threads of a workgroup.
-template <typename VoxelT, int LAYOUT, bool PK12>
+// BIG (volumes beyond 32-bit offsets, bricked layout only): X and Y hold ELEMENT offsets (their sum stays far
+// below 2^32) and Z holds its element offset / 16 (the z term, 64*bnx*bny*(k>>2) + 16*(k&3), is a multiple of 16
+// and reaches 2^33 at 2048^3): offset = X[i] + Y[j] + (uint64(Z[k]) << 4).
+template <typename VoxelT, int LAYOUT, bool PK12, bool BIG = false>
 __device__ __forceinline__ void build_axis_tables(const FrameParams &P, uint32_t *tab, int nthreads)
 {
+    static_assert(!BIG || (LAYOUT == 1 && !PK12 && BRICK_LX + BRICK_LY >= 4), "64-bit tables: bricked layout, z term a multiple of 16");
     const int na = P.nx + P.ny + P.nz;
     for (int e = (int)threadIdx.x; e < na; e += nthreads) {
         uint32_t t;
@@ -155,9 +159,17 @@ __device__ __forceinline__ void build_axis_tables(const FrameParams &P, uint32_t
                             : (BRICK_LY ? (j << BRICK_LX) + P.bstride_y * (j >> BRICK_LY) : P.bstride_y * j);
         } else {
             const uint32_t k = (uint32_t)(e - P.nx - P.ny);
+            if (BIG) {
+                // bstride_z is kept modulo 2^32 by the host for the 32-bit kernels: rebuild the term in 64 bits
+                const uint64_t bsz = 64ull * (uint64_t)(uint32_t)P.bnx * (uint64_t)(uint32_t)P.bny - (BRICK_LZ ? 64ull : 0ull);
+                const uint64_t tz = (BRICK_LZ ? ((uint64_t)k << (BRICK_LX + BRICK_LY)) + bsz * (uint64_t)(k >> BRICK_LZ) : bsz * (uint64_t)k);
+                tab[e] = (uint32_t)(tz >> 4);
+                continue;
+            }
             t = LAYOUT == 0 ? k * (uint32_t)P.ny * (uint32_t)P.nx
                             : (BRICK_LZ ? (k << (BRICK_LX + BRICK_LY)) + P.bstride_z * (k >> BRICK_LZ) : P.bstride_z * k);
         }
+        if (BIG) { tab[e] = t; continue; }
         tab[e] = PK12 ? (uint32_t)((3ull * (uint64_t)t) >> 1) : t * (uint32_t)sizeof(VoxelT);
     }
 }
@@ -196,6 +208,10 @@ static_assert(FAST_TF_WINDOW_MAX == FAST_LUT_MAX * 8 - FAST_TF_ENTRIES * 16, "vr
 // so the ~10 integer VALU ops of VoxelAddr become three LDS look-ups and one add; integer ops
 // issue at ~1.6x the cost of fp32 ops on gfx950 and are 40 % of the inner loop's issue time.
 constexpr int FAST_AXIS_TAB_MAX = 3072; // entries: nx + ny + nz (x 4 B = 12 KiB)
+// the same for volumes beyond 32-bit offsets (2048^3 = 6144 entries, 24 KiB); their classification table is
+// cut to 8 KiB -- 1024 (c,a) entries, or the 256 RGBA entries + 4096 index bytes -- so that three workgroups
+// still fit a CU
+constexpr int FAST_AXIS_TAB_BIG_MAX = 6144, FAST_BIG_LUT_FLOATS = 2048;
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c)
 {

@@ -268,9 +268,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
 {
     static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
     static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH == 8), "12-bit copy: u16 bricks through the address tables");
-    __shared__ float lut[LUT ? FAST_LUT_MAX * 2 : 4];       // 32 KiB: 4096 x (c,a) or 2048 x (r,g,b,a)
-    __shared__ uint32_t axis_tab[ATAB ? FAST_AXIS_TAB_MAX : 1];
-    static_assert(!ATAB || !BIG, "address tables hold 32-bit byte offsets");
+    __shared__ float lut[LUT ? (ATAB && BIG ? FAST_BIG_LUT_FLOATS : FAST_LUT_MAX * 2) : 4];   // 32 KiB: 4096 x (c,a) or 256 x (r,g,b,a) + index bytes
+    __shared__ uint32_t axis_tab[ATAB ? (BIG ? FAST_AXIS_TAB_BIG_MAX : FAST_AXIS_TAB_MAX) : 1];
+    static_assert(!(ATAB && BIG) || LAYOUT == 1, "64-bit address tables exist for the bricked layout");
     unsigned tx, ty;
     if (tile_table) {                                       // host-built longest-first order
         const uint32_t t = tile_table[blockIdx.x];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
     if (LUT || ATAB) {
         // tabulate only if some ray of the workgroup enters the volume
         if (__syncthreads_or(hit ? 1 : 0)) {
-            if (ATAB) build_axis_tables<VoxelT, LAYOUT, PK12>(P, axis_tab, (int)FAST_THREADS);
+            if constexpr (ATAB) build_axis_tables<VoxelT, LAYOUT, PK12, BIG>(P, axis_tab, (int)FAST_THREADS);
             const int n = LUT ? P.max_val - P.min_val + 1 : 0;
             for (int e = (int)threadIdx.x; e < n; e += (int)FAST_THREADS) {
                 const float s = (float)(P.min_val + e);          // == clamp(float(texel), fmin, fmax)
@@ -461,13 +461,14 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     voxel_of(qx, qy, qz, vi, vj, vk);
                     qx += dsx; qy += dsy; qz += dsz;
                 }
-                if (ATAB) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)(tab_x[vi] + tab_y[vj] + tab_z[vk]);   // bytes
+                if (ATAB && BIG) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)((uint64_t)(tab_x[vi] + tab_y[vj]) + ((uint64_t)tab_z[vk] << 4));   // elements
+                else if (ATAB) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)(tab_x[vi] + tab_y[vj] + tab_z[vk]);   // bytes
                 else off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
                 if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);   // odd x: upper 12 of the 16 bits
             }
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
-                if (ATAB) {
+                if (ATAB && !BIG) {
                     v[u] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[u], 0, 0)
                                                : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rs, (int)off[u], 0, 0);
                     continue;
@@ -1364,8 +1365,12 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
     // LDS address tables whenever offsets are 32-bit and nx + ny + nz entries fit; the 12-bit
     // packed copy (host: refreshPacked12) rides on them
-    constexpr bool CAN_ATAB = !BIG, CAN_PK12 = CAN_ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1;
-    const bool atab = CAN_ATAB && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
+    // (volumes beyond 32-bit offsets: 64-bit tables for the bricked layout, with a classification table cut to
+    // 8 KiB -- the window has to fit it)
+    constexpr bool CAN_ATAB = !BIG || LAYOUT == 1, CAN_PK12 = !BIG && sizeof(VoxelT) == 2 && LAYOUT == 1;
+    const int64_t win_width = (int64_t)P.max_val - (int64_t)P.min_val + 1;
+    const bool atab = CAN_ATAB && (BIG ? P.nx + P.ny + P.nz <= FAST_AXIS_TAB_BIG_MAX && (!lut || win_width <= (MODE >= 2 ? 4096 : FAST_BIG_LUT_FLOATS / 2))
+                                       : P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX);
     const bool pk12 = atab && CAN_PK12 && L.packed12 != nullptr;
 #define VR_LAUNCH2(TC, LT, P2, NC, SK)                                                                                    \
     (pk12 ? launch_fast<VoxelT, LAYOUT, TC, VIEW, BIG, LT, P2, (NC) && MODE == 0, MODE, SK, 8, CAN_ATAB, CAN_PK12>(P, L, vol, tf, fb, spp, rows, st) \
