@@ -8,7 +8,7 @@ while [ "$1" != "--" ]; do CGRP+=("$1"); shift; done
 shift
 cd "$(dirname "$0")/.."; REPO=$PWD; export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_$TAG; mkdir -p "$OUT"
-CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras $*"
 cd /tmp
 i=0
 for G in "${CGRP[@]}"; do

@@ -12,7 +12,7 @@ REPO=$PWD
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras $*"
 cd /tmp
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $CMD > "$OUT/stats.log" 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE"; do

@@ -680,11 +680,15 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     };
     // tv[0..3]: x0 tap in the low half, next storage element in the high half; tv[4..7]: the x1
     // taps of the lanes whose x1 lies elsewhere (brick / volume edge)
-    auto load_taps = [&](const uint32_t (&off)[8], bool pair, uint32_t *tv) {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            tv[k] = sizeof(VoxelT) == 1 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off[k], 0, 0)
-                                        : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off[k], 0, 0);
+    // reuse: 0 = fetch both z planes of the cell, 1 = this sample's near plane is the previous sample's far
+    // plane (the ray moved one voxel on in z inside the same (x, y) cell), 2 = same cell as the previous sample.
+    // Consecutive samples of a ray that runs along z share half or all of their taps: the words are taken
+    // from the previous sample when they are composited (consume), and their loads are not issued at all.
+    auto load_taps = [&](const uint32_t (&off)[8], bool pair, int reuse, uint32_t *tv) {
+        auto word = [&](uint32_t o) { return sizeof(VoxelT) == 1 ? (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)o, 0, 0)
+                                                                 : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0); };
+        if (reuse == 0) { tv[0] = word(off[0]); tv[1] = word(off[1]); }
+        if (reuse != 2) { tv[2] = word(off[2]); tv[3] = word(off[3]); }
         if (!pair) {
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -719,8 +723,11 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         }
     };
     int i = 0;
+    uint32_t poff0 = 0xffffffffu, poff1 = 0xffffffffu, poff2 = 0xffffffffu, poff3 = 0xffffffffu;   // pair-word offsets of the last sample issued
+    bool ppair = false;
+    uint32_t E0 = 0, E1 = 0, E2 = 0, E3 = 0;                 // pair words of the last sample composited
     // gathers of one batch (TRI_BATCH consecutive samples); positions advance with the shader's additions
-    auto issue = [&](uint32_t (&tv)[TRI_BATCH * 8], float (&wt)[TRI_BATCH * 3], bool (&pr)[TRI_BATCH]) {
+    auto issue = [&](uint32_t (&tv)[TRI_BATCH * 8], float (&wt)[TRI_BATCH * 3], bool (&pr)[TRI_BATCH], int (&ru)[TRI_BATCH]) {
         uint32_t off[TRI_BATCH][8];
 #pragma unroll
         for (int u = 0; u < TRI_BATCH; u++) {
@@ -736,15 +743,27 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
                 qx += dsx; qy += dsy; qz += dsz;
             }
             taps_of(fx, fy, fz, off[u], wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], pr[u]);
+            const bool can = pr[u] && ppair;
+            const bool near_is_far = off[u][0] == poff2 && off[u][1] == poff3, near_is_near = off[u][0] == poff0 && off[u][1] == poff1;
+            const bool far_is_far = off[u][2] == poff2 && off[u][3] == poff3;
+            ru[u] = can ? ((near_is_near && far_is_far) ? 2 : (near_is_far ? 1 : 0)) : 0;
+            poff0 = off[u][0]; poff1 = off[u][1]; poff2 = off[u][2]; poff3 = off[u][3]; ppair = pr[u];
         }
 #pragma unroll
-        for (int u = 0; u < TRI_BATCH; u++) load_taps(off[u], pr[u], &tv[8 * u]);
+        for (int u = 0; u < TRI_BATCH; u++) load_taps(off[u], pr[u], ru[u], &tv[8 * u]);
     };
     // returns true when the ray terminated (see the fast kernel: batch early-termination)
-    auto consume = [&](const uint32_t (&tv)[TRI_BATCH * 8], const float (&wt)[TRI_BATCH * 3], const bool (&pr)[TRI_BATCH]) -> bool {
+    auto consume = [&](const uint32_t (&tv)[TRI_BATCH * 8], const float (&wt)[TRI_BATCH * 3], const bool (&pr)[TRI_BATCH], const int (&ru)[TRI_BATCH]) -> bool {
         float c[TRI_BATCH], a[TRI_BATCH];
 #pragma unroll
-        for (int u = 0; u < TRI_BATCH; u++) shade(&tv[8 * u], pr[u], wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], c[u], a[u]);
+        for (int u = 0; u < TRI_BATCH; u++) {
+            uint32_t w[8];
+            w[0] = ru[u] == 0 ? tv[8 * u + 0] : (ru[u] == 1 ? E2 : E0); w[1] = ru[u] == 0 ? tv[8 * u + 1] : (ru[u] == 1 ? E3 : E1);
+            w[2] = ru[u] == 2 ? E2 : tv[8 * u + 2]; w[3] = ru[u] == 2 ? E3 : tv[8 * u + 3];
+            w[4] = tv[8 * u + 4]; w[5] = tv[8 * u + 5]; w[6] = tv[8 * u + 6]; w[7] = tv[8 * u + 7];
+            E0 = w[0]; E1 = w[1]; E2 = w[2]; E3 = w[3];
+            shade(w, pr[u], wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], c[u], a[u]);
+        }
         const float drgb0 = drgb, da0 = da;
         float da_last = 0.0f;
 #pragma unroll
@@ -769,18 +788,19 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         uint32_t va[TRI_BATCH * 8], vb[TRI_BATCH * 8];
         float wa[TRI_BATCH * 3], wb[TRI_BATCH * 3];
         bool pa[TRI_BATCH], pb[TRI_BATCH];
+        int ra[TRI_BATCH], rb[TRI_BATCH];
         int b = 0;
         bool fin = nb == 0;
-        if (!fin) issue(va, wa, pa);
+        if (!fin) issue(va, wa, pa, ra);
         for (;;) {
             if (__syncthreads_and(fin ? 1 : 0)) break;
 #pragma unroll 1
             for (int rep = 0; rep < 4 && !fin; rep++) {      // 16 samples between two lockstep votes
-                if (b + 1 < nb) issue(vb, wb, pb);
-                if (consume(va, wa, pa)) { done = true; fin = true; break; }
+                if (b + 1 < nb) issue(vb, wb, pb, rb);
+                if (consume(va, wa, pa, ra)) { done = true; fin = true; break; }
                 if (++b >= nb) { fin = true; break; }
-                if (b + 1 < nb) issue(va, wa, pa);
-                if (consume(vb, wb, pb)) { done = true; fin = true; break; }
+                if (b + 1 < nb) issue(va, wa, pa, ra);
+                if (consume(vb, wb, pb, rb)) { done = true; fin = true; break; }
                 if (++b >= nb) { fin = true; break; }
             }
         }
@@ -805,7 +825,7 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
             float ax, ay, az, c, a;
             bool pair;
             taps_of(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], off, ax, ay, az, pair);
-            load_taps(off, pair, tv);
+            load_taps(off, pair, 0, tv);
             shade(tv, pair, ax, ay, az, c, a);
             accumulate(c, a);
             qx += tsx; qy += tsy; qz += tsz;
