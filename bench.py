@@ -453,7 +453,8 @@ def kernel_source_hash() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted((ROOT / "volume-renderer_amd" / "csrc").glob("*.hip")) + sorted((ROOT / "volume-renderer_amd" / "csrc").glob("vr_frame.h")):
+    for f in sorted((ROOT / "volume-renderer_amd" / "csrc").glob("*.hip")) + sorted((ROOT / "volume-renderer_amd" / "csrc").glob("vr_*.h")) \
+            + sorted((ROOT / "volume-renderer_amd" / "csrc").glob("tile_schedule.*")):
         h.update(f.name.encode()); h.update(f.read_bytes())
     return h.hexdigest()[:16]
 

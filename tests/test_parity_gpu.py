@@ -747,12 +747,13 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
         lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
         alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
-        mip = tf = tri = accum = relay = stripes = False
+        mip = tf = tri = accum = relay = stripes = slab = False
         if extended:
-            mode = int(rng.integers(0, 12))
-            mip, tf, tri, accum = mode in (1, 8), mode in (2, 8), mode == 3, mode == 4     # 8: MIP through the transfer function
+            mode = int(rng.integers(0, 16))
+            mip, tf, tri, accum = mode in (1, 8, 13), mode in (2, 8, 14), mode == 3, mode == 4     # 8: MIP through the transfer function
             relay = mode in (5, 6)
-            stripes = mode == 7
+            stripes = mode in (7, 15)
+            slab = mode in (12, 13, 14, 15)       # the LDS-staged kernel (opt-in variant 4) wherever the trial is eligible for it
             if rng.random() < 0.2:
                 W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
         tf_lut = None
@@ -783,6 +784,8 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 r.setAccum(1)
             if relay:
                 r.setKernelVariant(3)
+            if slab:
+                r.setKernelVariant(4)
             rows = None
             if stripes:
                 rows = (4, int(rng.integers(0, 3)), 3)
@@ -800,7 +803,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                                         accum=int(accum), tf_rgba=tf_lut, trunc_grid=quirks & 1)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
                 what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
-                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} slab {slab} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
                 if rows:                                       # only this shard's rows are rendered
                     mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
                     assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)
