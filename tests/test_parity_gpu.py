@@ -919,3 +919,42 @@ def test_relay_kernel_full_size_shard(vra, cfg3):
     r.setRowStripes(1, 0, 1)
     assert np.array_equal(fast.view(np.uint32), relay.view(np.uint32))
     print(f"cfg3 shard 5/8: fast kernel {t_fast:.3f} ms, relay kernel {t_relay:.3f} ms")
+
+
+@pytest.mark.parametrize("mode", ["mip", "tf", "mip_tf", "top", "bottom", "mip_top", "tf_bottom"])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+def test_relay_kernel_modes_and_views(vra, oracle, dtype, mode):
+    """round 2: the relay kernel in MIP / transfer-function / view top-bottom (what a sparse multi-GPU shard
+    of those modes runs): forced with variant 3, against the oracle, both layouts, cubic (voxel-unit
+    marching) and anisotropic (certified division) volumes"""
+    rng = np.random.default_rng(123)
+    mip, tf = "mip" in mode, "tf" in mode
+    top, bottom = "top" in mode, "bottom" in mode
+    vmax = 255 if dtype == np.uint8 else 4095
+    for dims, spacing in (((64, 64, 64), (1.0, 1.0, 1.0)), ((40, 56, 24), (1.0, 0.7, 1.9))):
+        vol = rand_volume(rng, dims, dtype, smooth=True)
+        for layout in (0, 1):
+            with make_renderer(vra, (120, 88)) as r:
+                r.setQuirks(0)
+                r.setLayout(layout)
+                r.setKernelVariant(3)
+                r.setVolume(vol, spacing)
+                r.setWindow(vmax // 20, vmax - vmax // 10)
+                alpha = 0.4 if mip else 0.04
+                r.setAlpha(alpha)
+                r.setMIP(mip)
+                tf_lut = None
+                if tf:
+                    r.setTransferFunction([0, 90, 160, 255], [[0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
+                    tf_lut = r.getTransferLut()
+                r.setInitialCameraRotation(top, bottom)
+                for name, block in orbit_blocks(oracle)[:3]:
+                    r.setCameraBlock(block)
+                    r.render()
+                    assert r.last_kernel_name == "raymarch_relay_kernel", (mode, dims, layout, name)
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    p = oracle.OracleParams(120, 88, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=vmax // 20, max_val=vmax - vmax // 10,
+                                            is_mip=int(mip), view_top=int(top), view_bottom=int(bottom), tf_rgba=tf_lut)
+                    want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                    assert_same(got, want, spp, want_spp, what=f"relay {mode} {dims} {np.dtype(dtype).name} layout {layout} {name}")

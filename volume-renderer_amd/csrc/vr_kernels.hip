@@ -858,7 +858,8 @@ constexpr int RELAY_WAVES = 4, RELAY_BATCH = 8;
 constexpr int RELAY_TILES = 2, RELAY_THREADS = 64 * RELAY_WAVES * RELAY_TILES;
 
 struct RelayState {
-    float rgb[2][64];
+    float rgb[2][64];      // red (== green == blue in the grey modes)
+    float g[2][64], b[2][64];   // green / blue: only the transfer-function modes carry them
     float a[2][64];
     int i[2][64];
     float pos[2][3][64];   // ray position at the start of batch n (slot n & 1)
@@ -868,9 +869,11 @@ struct RelayState {
     unsigned final_n;      // the state slot holding the result is final_n & 1
 };
 
-template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP, bool ATAB, bool PK12>
+// VIEW / MODE as in the fast kernel (round 2: every mode and view of a sparse shard gets the relay)
+template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP, bool ATAB, bool PK12, int VIEW, int MODE>
 __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const FrameParams P,
                                                              const VoxelT *__restrict__ vol,
+                                                             const float4 *__restrict__ tf,
                                                              const uint32_t vol_bytes,
                                                              float4 *__restrict__ fb,
                                                              uint32_t *__restrict__ spp,
@@ -910,17 +913,33 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         hit = intersect_ray_aabb(P, ray, t_min, t_max);
     }
     const int any_hit = __syncthreads_or(hit ? 1 : 0);
+    static_assert(MODE < 2 || LUT, "the transfer-function modes classify through the table");
     if (LUT && any_hit) {
         const int n = P.max_val - P.min_val + 1;
         for (int e = (int)threadIdx.x; e < n; e += RELAY_THREADS) {
             const float s = (float)(P.min_val + e);
             const float v = div_cert(s - P.fmin, P.fden, P.rden);
-            const float a = v * P.alpha_scale;
-            lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
+            if (MODE >= 2) {                                     // two-level table, as in the fast kernel
+                int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
+                idx = clampi(idx, 0, P.tf_len - 1);
+                reinterpret_cast<uint8_t *>(lut)[FAST_TF_ENTRIES * 16 + e] = (uint8_t)idx;
+            } else {
+                const float a = v * P.alpha_scale;
+                lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
+            }
+        }
+        if (MODE >= 2) {
+            for (int e = (int)threadIdx.x; e < P.tf_len; e += RELAY_THREADS) {
+                const float4 t = tf[e];
+                const float a = t.w * P.alpha_scale;
+                if (MODE == 3) { lut[4 * e + 0] = t.x * P.alpha_scale; lut[4 * e + 1] = t.y * P.alpha_scale; lut[4 * e + 2] = t.z * P.alpha_scale; }
+                else { lut[4 * e + 0] = t.x * a; lut[4 * e + 1] = t.y * a; lut[4 * e + 2] = t.z * a; }
+                lut[4 * e + 3] = a;
+            }
         }
     }
     if (ATAB && any_hit) build_axis_tables<VoxelT, LAYOUT, PK12>(P, axis_tab, RELAY_THREADS);
-    if (w == 0) { rs.rgb[0][lane] = 0.0f; rs.a[0][lane] = 0.0f; rs.i[0][lane] = 0; }
+    if (w == 0) { rs.rgb[0][lane] = 0.0f; rs.g[0][lane] = 0.0f; rs.b[0][lane] = 0.0f; rs.a[0][lane] = 0.0f; rs.i[0][lane] = 0; }
     if (w == 0 && lane == 0) { rs.seq = 0u; rs.pseq = 0u; rs.stop = 0u; rs.final_n = 0u; }
     __syncthreads();
 
@@ -938,10 +957,11 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
 
     // marching units: voxels for POW2 (see the fast kernel), box units otherwise.  Only the
     // step is kept in registers; the position itself lives in LDS between wavefronts.
-    const float Sx = P.fdim[0], Sy = P.fdim[1], Sz = P.fdim[2];
+    // (per box axis the scale is the dimension of the voxel axis it maps to: y and z swap in the rotated views)
+    const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
     const float mx = POW2 ? dsx * Sx : dsx, my = POW2 ? dsy * Sy : dsy, mz = POW2 ? dsz * Sz : dsz;
     const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
-    const int lut_bias = -8 * P.min_val;
+    const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
 
     // The ray positions travel the same way as the compositing state: the wavefront that
     // generated the addresses of batch n publishes the position at the start of batch n+1
@@ -976,13 +996,20 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             for (int u = 0; u < RELAY_BATCH; u++) {
                 int vi, vj, vk;
                 if (POW2) {
-                    vi = (int)(x + Hx); vj = (int)(y + Hy); vk = (int)(Sz - (z + Hz));
+                    const float ux = x + Hx, uy = y + Hy, uz = Sz - (z + Hz);
+                    float fx = ux, fy = uy, fz = uz;
+                    if (VIEW == 1) { fy = Sz - uz; fz = uy; }
+                    else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                    vi = (int)fx; vj = (int)fy; vk = (int)fz;
                 } else {
                     const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
                     const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
                     float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
                     uz = 1.0f - uz;
-                    vi = (int)(ux * P.fdim[0]); vj = (int)(uy * P.fdim[1]); vk = (int)(uz * P.fdim[2]);
+                    float tcx = ux, tcy = uy, tcz = uz;
+                    if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                    else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+                    vi = (int)(tcx * P.fdim[0]); vj = (int)(tcy * P.fdim[1]); vk = (int)(tcz * P.fdim[2]);
                 }
                 if (ATAB) off[u] = tab_x[vi] + tab_y[vj] + tab_z[vk];                    // bytes
                 else off[u] = VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk);
@@ -1005,10 +1032,16 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         }
         return need;
     };
-    auto classify = [&](uint32_t texel, float &c, float &a) {
+    auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
         if (LUT) {
             int t = (int)texel;
             if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);
+            if (MODE >= 2) {
+                const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[(uint32_t)(t + lut_bias)];
+                const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
+                c = q.x; cg = q.y; cb = q.z; a = q.w;
+                return;
+            }
             const float2 ca = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lut) + (uint32_t)((t << 3) + lut_bias));
             c = ca.x; a = ca.y;
         } else {
@@ -1020,44 +1053,57 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         }
     };
     float da_seen = 0.0f;
+    // one sample onto the destination: front-to-back composite, or MIP's running maximum (see the fast kernel)
+    auto accumulate = [&](float &drgb, float &dg, float &db, float &da, float c, float cg, float cb, float a) {
+        if (MODE == 1) {
+            if (da < a) da = a;
+        } else if (MODE == 3) {
+            if (da < a) { drgb = c; dg = cg; db = cb; da = a; }
+        } else {
+            const float om = 1.0f - da;
+            drgb += c * om;
+            if (MODE == 2) { dg += cg * om; db += cb * om; }
+            da += a * om;
+        }
+    };
     // take over the recurrence for batch n, composite, hand it on
     auto relay = [&](int n, const uint32_t (&v)[RELAY_BATCH], uint32_t nib, bool valid) {
-        float c[RELAY_BATCH], a[RELAY_BATCH];
+        float c[RELAY_BATCH], cg[RELAY_BATCH], cb[RELAY_BATCH], a[RELAY_BATCH];
         if (valid) {
 #pragma unroll
-            for (int u = 0; u < RELAY_BATCH; u++)
-                classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], a[u]);
+            for (int u = 0; u < RELAY_BATCH; u++) {
+                cg[u] = cb[u] = 0.0f;
+                classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
+            }
         }
         if (stopped || !wait_for(&rs.seq, n)) { stopped = true; return; }
         const int slot = n & 1;
-        float drgb = rs.rgb[slot][lane], da = rs.a[slot][lane];
+        float drgb = rs.rgb[slot][lane], da = rs.a[slot][lane], dg = 0.0f, db = 0.0f;
+        if (MODE >= 2) { dg = rs.g[slot][lane]; db = rs.b[slot][lane]; }
         int i = rs.i[slot][lane];
         if (valid) {
-            const float drgb0 = drgb, da0 = da;
+            const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             float da_last = 0.0f;
 #pragma unroll
             for (int u = 0; u < RELAY_BATCH; u++) {
                 if (u == RELAY_BATCH - 1) da_last = da;
-                const float om = 1.0f - da;
-                drgb += c[u] * om;
-                da += a[u] * om;
+                accumulate(drgb, dg, db, da, c[u], cg[u], cb[u], a[u]);
             }
             if (da_last < 0.95f) {
                 i += RELAY_BATCH;
             } else {                                     // the batch in which the ray terminates: literal per-sample tests
-                drgb = drgb0; da = da0;
+                drgb = drgb0; dg = dg0; db = db0; da = da0;
 #pragma unroll
                 for (int u = 0; u < RELAY_BATCH; u++) {
                     if (da >= 0.95f) break;
-                    const float om = 1.0f - da;
-                    drgb += c[u] * om;
-                    da += a[u] * om;
+                    accumulate(drgb, dg, db, da, c[u], cg[u], cb[u], a[u]);
                     i++;
                 }
             }
         }
         da_seen = da;
         rs.rgb[slot ^ 1][lane] = drgb; rs.a[slot ^ 1][lane] = da; rs.i[slot ^ 1][lane] = i;
+        if (MODE >= 2) { rs.g[slot ^ 1][lane] = dg; rs.b[slot ^ 1][lane] = db; }
         // does any ray of the tile need another batch?  (terminated rays and rays whose prefix
         // ends here do not)
         const bool more = hit && da < 0.95f && n + 1 < nb;
@@ -1092,7 +1138,8 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     __syncthreads();
     if (w != 0) return;
     const unsigned fin = rs.final_n;                     // == nbmax unless the tile stopped early
-    float drgb = rs.rgb[fin & 1][lane], da = rs.a[fin & 1][lane];
+    float drgb = rs.rgb[fin & 1][lane], da = rs.a[fin & 1][lane], dg = 0.0f, db = 0.0f;
+    if (MODE >= 2) { dg = rs.g[fin & 1][lane]; db = rs.b[fin & 1][lane]; }
     int i = rs.i[fin & 1][lane];
     {
         // a ray that still needs its tail finished its prefix at batch nb <= fin <= pseq, and its
@@ -1109,21 +1156,24 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
             float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
             uz = 1.0f - uz;
-            if (ux > 1.0f || uy > 1.0f || uz > 1.0f || ux < 0.0f || uy < 0.0f || uz < 0.0f || da >= 0.95f) break;
-            const int vi = min((int)(ux * P.fdim[0]), nxm1);
-            const int vj = min((int)(uy * P.fdim[1]), nym1);
-            const int vk = min((int)(uz * P.fdim[2]), nzm1);
-            float c, a;
-            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, a);
-            const float om = 1.0f - da;
-            drgb += c * om;
-            da += a * om;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
+            const int vi = min((int)(tcx * P.fdim[0]), nxm1);
+            const int vj = min((int)(tcy * P.fdim[1]), nym1);
+            const int vk = min((int)(tcz * P.fdim[2]), nzm1);
+            float c, cg = 0.0f, cb = 0.0f, a;
+            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, cg, cb, a);
+            accumulate(drgb, dg, db, da, c, cg, cb, a);
             qx += tsx; qy += tsy; qz += tsz;
         }
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
-    store_pixel(P, fb, pix, drgb, drgb, drgb, da);
+    if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
+    else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
+    else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
     if (spp) spp[pix] = hit ? (uint32_t)i : 0u;
 }
 
@@ -1324,18 +1374,22 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
     return hipGetLastError();
 }
 
-// the relay kernel serves the headline shape (grey composite, default view, 32-bit offsets,
-// no skipping); L.sparse_shard (host: fewer than 256 active tiles, or vr_set_kernel_variant)
-// is its on/off switch
+// The relay kernel serves sparse launches (host: fewer than 256 active tiles -- one rank's shard of a multi-GPU
+// frame -- or vr_set_kernel_variant 3) with 32-bit offsets and no skipping.  The headline shape (grey
+// composite, default view) has every table / clamp / packing variant; the other modes and views (MIP, transfer
+// function, view top / bottom: round 2) are built for the configuration such shards actually have -- a
+// classification table and per-axis address tables in LDS (+ the 12-bit packed copy) -- and anything else stays
+// with the fast kernel.
 static bool relay_selected(const FrameParams &P, const LaunchConfig &L)
 {
-    return L.sparse_shard && L.tile_table && !L.mip && P.tf_len <= 1 && !L.big_offsets && P.view_top != 1 &&
-           P.view_bottom != 1 && !(P.skip_empty != 0 && L.skip_grid != nullptr);
+    if (!(L.sparse_shard && L.tile_table && !L.big_offsets && !(P.skip_empty != 0 && L.skip_grid != nullptr))) return false;
+    const bool headline = !L.mip && P.tf_len <= 1 && P.view_top != 1 && P.view_bottom != 1;
+    return headline || (L.use_lut != 0 && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX);
 }
 
-template <typename VoxelT, int LAYOUT>
-static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, const void *vol, float4 *fb, uint32_t *spp,
-                                 hipStream_t st)
+template <typename VoxelT, int LAYOUT, int VIEW, int MODE>
+static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                 uint32_t *spp, hipStream_t st)
 {
     const bool lut = L.use_lut != 0, noclamp = lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
@@ -1345,29 +1399,42 @@ static hipError_t dispatch_relay(const FrameParams &P, const LaunchConfig &L, co
     const bool pk12 = atab && CAN_PK12 && L.packed12 != nullptr;
 #define VR_RELAY2(TC, LT, P2, NC, AT, PK)                                                                         \
     do {                                                                                                          \
-        hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC, AT, PK>), grid, block, 0, st, P,  \
-                           (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table,                     \
+        hipLaunchKernelGGL((raymarch_relay_kernel<VoxelT, LAYOUT, TC, LT, P2, NC, AT, PK, VIEW, MODE>), grid, block, 0, st, P, \
+                           (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table,                 \
                            (PK) ? L.packed12 : nullptr, (PK) ? L.packed12_bytes : 0u);                             \
         return hipGetLastError();                                                                                 \
     } while (0)
+    if constexpr (VIEW == 0 && MODE == 0) {
 #define VR_RELAY(TC, LT, P2, NC)                                                                                  \
     do {                                                                                                          \
         if (pk12) VR_RELAY2(TC, LT, P2, NC, true, CAN_PK12);                                                      \
         if (atab) VR_RELAY2(TC, LT, P2, NC, true, false);                                                         \
         VR_RELAY2(TC, LT, P2, NC, false, false);                                                                  \
     } while (0)
-    if (L.divmode_tc == DIV_CERT) {
-        if (lut) { if (noclamp) VR_RELAY(DIV_CERT, true, false, true); else VR_RELAY(DIV_CERT, true, false, false); }
-        VR_RELAY(DIV_CERT, false, false, false);
-    }
-    if (pow2) {
-        if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, true, true); else VR_RELAY(DIV_UNIT, true, true, false); }
-        VR_RELAY(DIV_UNIT, false, true, false);
-    }
-    if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, false, true); else VR_RELAY(DIV_UNIT, true, false, false); }
-    VR_RELAY(DIV_UNIT, false, false, false);
-#undef VR_RELAY2
+        if (L.divmode_tc == DIV_CERT) {
+            if (lut) { if (noclamp) VR_RELAY(DIV_CERT, true, false, true); else VR_RELAY(DIV_CERT, true, false, false); }
+            VR_RELAY(DIV_CERT, false, false, false);
+        }
+        if (pow2) {
+            if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, true, true); else VR_RELAY(DIV_UNIT, true, true, false); }
+            VR_RELAY(DIV_UNIT, false, true, false);
+        }
+        if (lut) { if (noclamp) VR_RELAY(DIV_UNIT, true, false, true); else VR_RELAY(DIV_UNIT, true, false, false); }
+        VR_RELAY(DIV_UNIT, false, false, false);
 #undef VR_RELAY
+    } else {
+        // relay_selected() has checked: table + address tables
+#define VR_RELAY(TC, P2)                                                                                          \
+    do {                                                                                                          \
+        if (pk12) VR_RELAY2(TC, true, P2, false, true, CAN_PK12);                                                 \
+        VR_RELAY2(TC, true, P2, false, true, false);                                                              \
+    } while (0)
+        if (L.divmode_tc == DIV_CERT) VR_RELAY(DIV_CERT, false);
+        if (pow2) VR_RELAY(DIV_UNIT, true);
+        VR_RELAY(DIV_UNIT, false);
+#undef VR_RELAY
+    }
+#undef VR_RELAY2
 }
 
 template <typename VoxelT, int LAYOUT, int VIEW, bool BIG, int MODE>
@@ -1377,9 +1444,10 @@ static hipError_t dispatch_fast3(const FrameParams &P, const LaunchConfig &L, co
     // the no-clamp specialisation is kept for the headline mode only (compile time)
     const bool lut = L.use_lut != 0, noclamp = MODE == 0 && lut && L.lut_noclamp != 0;
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-    // sparse shards of the headline shape: four wavefronts relay one 8x8 tile
-    if (MODE == 0 && VIEW == 0 && !BIG && relay_selected(P, L))
-        return dispatch_relay<VoxelT, LAYOUT>(P, L, vol, fb, spp, st);
+    // sparse shards: four wavefronts relay one 8x8 tile
+    if constexpr (!BIG) {
+        if (relay_selected(P, L)) return dispatch_relay<VoxelT, LAYOUT, VIEW, MODE>(P, L, vol, tf, fb, spp, st);
+    }
     // the skipping-free build exists for the headline shape only (MODE 0, default view)
     constexpr bool HEADLINE = MODE == 0 && VIEW == 0;
     const bool noskip = HEADLINE && !(P.skip_empty != 0 && L.skip_grid != nullptr);
