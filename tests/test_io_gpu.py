@@ -211,3 +211,35 @@ def test_external_target_stream_and_compact_shard(vra, oracle):
         r.setRowRange(0, -1)
         r.render()
         assert np.array_equal(r.readPixels().view(np.uint32), full.view(np.uint32))
+
+
+@pytest.mark.parametrize("which,datasize,size", [("VR_DATA_BONSAI", 1, (1280, 720)), ("VR_DATA_HEAD", 2, (1920, 1080))], ids=["cfg1_bonsai_raw", "cfg2_head_pvm"])
+def test_reference_datasets_when_supplied(vra, oracle, which, datasize, size):
+    """BASELINE configs 1 / 2 on the reference's own datasets (Bonsai .RAW, Head-CT .PVM; upstream git-ignores
+    them, README.md:6-7): set VR_DATA_BONSAI / VR_DATA_HEAD to the files to run the reference's default pipeline
+    on them (readVolumeData, default window, +1000 quirk for 16 bit) against the oracle on sparse rows.
+    Skipped when the files are not on the box (synthetic stand-ins of the same shape run elsewhere)."""
+    import os
+
+    path = os.environ.get(which)
+    if not path or not os.path.exists(path):
+        pytest.skip(f"{which} not set")
+    with vra.RendererCore(0) as r:
+        r.setup(size)
+        assert r.loadShader("VolumeRenderer.cs")
+        r.readVolumeData(path, datasize)
+        assert r.takeMessage()[0] == "File Loaded!"
+        lo, hi = r.window
+        (dims, spacing, _) = r.dims
+        r.setAlpha(0.05)
+        r.render()
+        got = r.readPixels()
+        vol = r.readVolume()
+        block = r.getCameraBlock()
+    off = 1000 if datasize == 2 else 0                      # Q10: the uniform carries +1000 for 16-bit data
+    p = oracle.OracleParams(size[0], size[1], cam=block, alpha_scale=0.05, voxel_size=tuple(spacing), min_val=lo + off, max_val=hi + off, threads=8)
+    want = np.zeros_like(got)
+    for y in range(size[1] // 8, size[1], size[1] // 8):
+        p.row_begin, p.row_end = y, y + 1
+        oracle.render(vol, p, out=want)
+        assert np.array_equal(got[y].view(np.uint32), want[y].view(np.uint32)), f"{which} row {y}"

@@ -541,13 +541,19 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 if (skip_on) cell_next = probe(0);
                 skip_a = issue(va, nib_a);
             }
-            for (;;) {
-                if (__syncthreads_and(fin ? 1 : 0)) break;
+            // lockstep: one plain barrier per 16 samples; every 4th doubles as the vote "all rays finished"
+            // (__syncthreads_and is three barriers and a cross-lane reduction: 0.464 -> 0.458 ms on cfg3)
+            for (unsigned it = 0;; it++) {
+                if ((it & 3u) == 0u) { if (__syncthreads_and(fin ? 1 : 0)) break; }
+                else __syncthreads();
                 if (!fin) {
                     if (b + 1 < nb) skip_b = issue(vb, nib_b);
                     if (consume(va, skip_a, nib_a)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
+#if defined(VR_EXPERIMENTS) && defined(VR_X_LOCKSTEP8)
+                __syncthreads();
+#endif
                 if (!fin) {
                     if (b + 1 < nb) skip_a = issue(va, nib_a);
                     if (consume(vb, skip_b, nib_b)) { done = true; fin = true; }
