@@ -17,6 +17,7 @@ r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
 r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004)
 if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+r.setKernelVariant(4)
 r.render()
 print("kernel", r.last_kernel_name)
 _, spp = r.countSamples(per_pixel=True)

@@ -99,14 +99,26 @@ __device__ __forceinline__ float wave_max_f(float v)
 template <typename T> __device__ __forceinline__ T sel3(int ax, T v0, T v1, T v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
 constexpr int SLAB_NW = 8, SLAB_THREADS = 64 * SLAB_NW;   // one 32x16-pixel tile per workgroup, like the fast kernel
-constexpr int SLAB_PHASE = 4;          // samples per phase (one brick layer at one voxel per step)
+#if defined(VR_EXPERIMENTS) && defined(VR_X_PHASE)
+constexpr int SLAB_PHASE = VR_X_PHASE;
+#else
+constexpr int SLAB_PHASE = 8;          // samples per phase = per workgroup barrier (two brick layers at one voxel per step; 4: 0.85 ms, 8: 0.68 ms on cfg3)
+#endif
 #if defined(VR_EXPERIMENTS) && defined(VR_X_EPOCH)
 constexpr int SLAB_EPOCH = VR_X_EPOCH;
 #else
-constexpr int SLAB_EPOCH = 32;         // phases per load plan / between two anchors
+constexpr int SLAB_EPOCH = 16;         // phases per load plan / between two anchors
 #endif
-constexpr int SLAB_LA = 3;             // phases of prefetch distance asked for (the ring depth may allow less)
+#if defined(VR_EXPERIMENTS) && defined(VR_X_LA)
+constexpr int SLAB_LA = VR_X_LA;
+#else
+constexpr int SLAB_LA = 2;             // phases of prefetch distance asked for (the ring depth may allow less)
+#endif
+#if defined(VR_EXPERIMENTS) && defined(VR_X_LDSKB)
+constexpr int SLAB_LDS_BYTES = VR_X_LDSKB * 1024 - 512;
+#else
 constexpr int SLAB_LDS_BYTES = 80 * 1024 - 512;           // two workgroups per CU (160 KiB)
+#endif
 constexpr float SLAB_MARGIN = 0.0625f; // voxels: covers the rounding of the iterated positions over an epoch (< 2^-7 voxel for N <= 4096)
 constexpr int SLAB_MAX_PIECES = 2;     // 1-KiB pieces per wavefront per layer
 
@@ -124,8 +136,11 @@ struct SlabCfg {
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 + LUT_ENTRIES : (sizeof(VoxelT) == 1 ? LUT_ENTRIES * 8 : 16);
     static constexpr int TAB_ENTRIES = sizeof(VoxelT) == 1 ? 6144 : 3072;   // nx + ny + nz
     static constexpr int MISC_BYTES = 1024;
-    static constexpr int RING_RAW = SLAB_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES;
-    static constexpr int RING_BYTES = (RING_RAW > 65535 ? 65535 : RING_RAW) / SLOT * SLOT;   // offsets are 16-bit
+    // torus tables: 16-bit entries while the ring stays below 64 KiB (two workgroups per CU), 32-bit beyond
+    static constexpr bool WIDE_TAB = SLAB_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES > 65535 + 16384;
+    static constexpr int TAB_BYTES = TAB_ENTRIES * (WIDE_TAB ? 4 : 2);
+    static constexpr int RING_RAW = SLAB_LDS_BYTES - LUT_BYTES - TAB_BYTES - MISC_BYTES;
+    static constexpr int RING_BYTES = (!WIDE_TAB && RING_RAW > 65535 ? 65535 : RING_RAW) / SLOT * SLOT;
     static constexpr int CAP = RING_BYTES / SLOT;                           // brick slots
     static constexpr int LAYER_SLOTS_MAX = SLAB_MAX_PIECES * SLAB_NW * 64 / CH;
 };
@@ -145,7 +160,8 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     constexpr int BATCH = SLAB_PHASE;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::RING_BYTES];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
-    __shared__ uint16_t tab[C::TAB_ENTRIES];
+    using TabT = typename std::conditional<C::WIDE_TAB, uint32_t, uint16_t>::type;
+    __shared__ TabT tab[C::TAB_ENTRIES];
     __shared__ __attribute__((aligned(16))) uint4 plan[SLAB_EPOCH];
     __shared__ float red[SLAB_NW][8];
     __shared__ int geo[8];
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             const uint32_t stride = axis == ax_a ? (uint32_t)C::SLOT : (axis == ax_b ? (uint32_t)(RA * C::SLOT) : layer_bytes);
             const uint32_t in = (uint32_t)(i & 3) << (2 * axis);          // element offset inside the brick: x + 4y + 16z
             const uint32_t inb = PK12 ? (3u * in) >> 1 : in;               // bytes (12-bit stream: floor(1.5 e), exact for the even y/z terms)
-            tab[e] = (uint16_t)((uint32_t)((i >> 2) % R) * stride + inb);
+            tab[e] = (TabT)((uint32_t)((i >> 2) % R) * stride + inb);
         }
 #pragma unroll
         for (int q = 0; q < SLAB_MAX_PIECES; q++) {
@@ -322,12 +338,13 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         auto trail = [&](float j1, float j2) { return sg > 0 ? blo(ma, j1, j2) : -bhi(ma, j1, j2); };
         auto lead = [&](float j1, float j2) { return sg > 0 ? bhi(ma, j1, j2) : -blo(ma, j1, j2); };
         const int i = (int)(lane & (SLAB_EPOCH - 1));
-        const float j0 = (float)(BATCH * i);
-        const int trail_i = trail(j0, j0 + 3.0f), lead_i = lead(j0, j0 + 3.0f);
-        const int lead_next = lead(j0 + 4.0f, j0 + 7.0f);
-        const int f_i = min(lead(j0 + 4.0f * SLAB_LA, j0 + 4.0f * SLAB_LA + 3.0f), trail_i + rz - 1) + 1;
-        const int f_p = min(lead(j0 - 4.0f + 4.0f * SLAB_LA, j0 - 1.0f + 4.0f * SLAB_LA), trail(j0 - 4.0f, j0 - 1.0f) + rz - 1) + 1;
-        const int fc = cold ? trail(0.0f, 3.0f) : fcarry;
+        constexpr float PH = (float)BATCH, LAST = (float)(BATCH - 1);       // a phase = samples j0 .. j0 + LAST
+        const float j0 = PH * (float)i;
+        const int trail_i = trail(j0, j0 + LAST), lead_i = lead(j0, j0 + LAST);
+        const int lead_next = lead(j0 + PH, j0 + PH + LAST);
+        const int f_i = min(lead(j0 + PH * SLAB_LA, j0 + PH * SLAB_LA + LAST), trail_i + rz - 1) + 1;
+        const int f_p = min(lead(j0 - PH + PH * SLAB_LA, j0 - 1.0f + PH * SLAB_LA), trail(j0 - PH, j0 - 1.0f) + rz - 1) + 1;
+        const int fc = cold ? trail(0.0f, LAST) : fcarry;
         const int Fb = i == 0 ? fc : max(fc, f_p);
         const int Fa = max(max(fc, f_i), Fb);
         const int n = Fa - Fb;
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         if (lead_i >= Fa && i == 0 && cold) over = true;
         if (lead_next >= Fa) over = true;                               // the ring cannot hold what the next phase needs
         if (lead_i - trail_i + 1 > rz) over = true;
-        if (n > (cold && i == 0 ? 15 : 4)) over = true;
+        if (n > (cold && i == 0 ? 15 : 6)) over = true;
         int lo_a = 0, lo_b = 0, dda = 0, ddb = 0;
         if (n > 0) {
             const int lastb = sg * (Fa - 1);                             // brick index of the last layer requested now
@@ -347,7 +364,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             if (sg > 0) jx = ((float)(4 * (lastb + 1)) - (sel3(ma, Amin0, Amin1, Amin2) - MG)) / sel3(ma, dmn0, dmn1, dmn2);
             else jx = ((sel3(ma, Amax0, Amax1, Amax2) + MG) - (float)(4 * lastb)) / -sel3(ma, dmx0, dmx1, dmx2);
             if (!(jx < j0 + 600.0f)) over = true;
-            const float j2 = fmaxf(jx, j0 + 3.0f) + 1.0f;
+            const float j2 = fmaxf(jx, j0 + LAST) + 1.0f;
             lo_a = blo(a_, j0, j2); lo_b = blo(b_, j0, j2);
             dda = bhi(a_, j0, j2) - lo_a; ddb = bhi(b_, j0, j2) - lo_b;
             if (dda >= ra || ddb >= rb) over = true;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     };
 
     // ---- one phase of the gathers: BATCH consecutive samples from the current position
-    const uint16_t *tab_x = tab, *tab_y = tab + P.nx, *tab_z = tab + P.nx + P.ny;
+    const TabT *tab_x = tab, *tab_y = tab + P.nx, *tab_z = tab + P.nx + P.ny;
     auto advance_index = [&](int &vi, int &vj, int &vk) {
         if (POW2) {
             const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     uint32_t nib = 0;
     bool prepared = false;
     uint4 entry_next = make_uint4(0u, 0u, 0u, 0u);   // the next phase's plan entry, read before the barrier
-#ifdef VR_EXPERIMENTS
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
     unsigned st_epochs = 0, st_cold = 0, st_fallback = 0;
 #endif
     for (int p = 0; p < nbmax; p++) {
@@ -523,7 +540,12 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                     const float dlo = sel3(ma, dmn0, dmn1, dmn2), dhi = sel3(ma, dmx0, dmx1, dmx2);
                     const int sg = (dlo > 0.0f && dhi > 0.0f) ? 1 : ((dlo < 0.0f && dhi < 0.0f) ? -1 : 0);
                     const float vslow = fminf(fabsf(dlo), fabsf(dhi)), vfast = fmaxf(fabsf(dlo), fabsf(dhi));
-                    const float horizon = fminf((float)(BATCH * SLAB_EPOCH * 2), (float)steps_left) + (float)(BATCH * SLAB_LA + 8);
+#if defined(VR_EXPERIMENTS) && defined(VR_X_HORIZON)
+                    constexpr int HORIZON_EPOCHS = VR_X_HORIZON;
+#else
+                    constexpr int HORIZON_EPOCHS = 1;
+#endif
+                    const float horizon = fminf((float)(BATCH * SLAB_EPOCH * HORIZON_EPOCHS), (float)steps_left) + (float)(BATCH * SLAB_LA + 8);
                     auto span = [&](int x) { return (sel3(x, Amax0, Amax1, Amax2) - sel3(x, Amin0, Amin1, Amin2)) + horizon * (sel3(x, dmx0, dmx1, dmx2) - sel3(x, dmn0, dmn1, dmn2)) + 2.0f * SLAB_MARGIN; };
                     status = 2;
                     if (sg != 0 && vslow >= 0.125f) {
@@ -537,7 +559,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                         const int rzmin = (int)((span(ma) + vfast * (float)(2 * BATCH)) * 0.25f) + 2;
                         if (ra <= 31 && rb <= 31 && ra * rb <= C::LAYER_SLOTS_MAX) {
                             const int rz = min(min(C::CAP / (ra * rb), 15), sel3(ma, nbr0, nbr1, nbr2) + 1);   // <= 15: a cold start names all of them in one entry
-                            if (rz >= rzmin && rz >= 2) {
+                            if (rz >= rzmin - 1 && rz >= 2) {        // (rzmin is the worst brick alignment; the per-phase checks of plan_epoch decide)
                                 if (!(__any(plan_epoch(ma, sg, ra, rb, rz, true, 0, steps_left, entry, f_after) ? 1 : 0) != 0)) {
                                     status = 1;
                                     if (lane == 0) { geo[0] = ma; geo[1] = sg; geo[2] = ra; geo[3] = rb; geo[4] = rz; }
@@ -558,7 +580,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             __syncthreads();
             const int status = uniform_i(geo[5]);
             epoch_staged = status != 2;
-#ifdef VR_EXPERIMENTS
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
             st_epochs++; st_cold += status == 1; st_fallback += status == 2;
 #endif
             if (status == 1) {
@@ -685,7 +707,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
-#ifdef VR_EXPERIMENTS      // per-tile load-plan statistics instead of the fetch count of the tile's first pixel
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)      // per-tile load-plan statistics instead of the fetch count of the tile's first pixel
     if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | st_epochs | (st_cold << 8) | (st_fallback << 16) | ((unsigned)(RA * RB) << 24 & 0x7f000000u); return; }
 #endif
     if (spp) spp[pix] = (uint32_t)i;
