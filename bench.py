@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--gather-format", choices=("auto", "rgba", "ga"), default="auto",
                     help="N > 1: what the all_gather moves -- RGBA32F, or (grey, alpha) float2 in the grey modes "
                          "(r == g == b there; expanded to RGBA after the gather); auto = ga when the mode is grey")
+    ap.add_argument("--collective", choices=("gather", "all_gather"), default="gather",
+                    help="N > 1: gather the shards to rank 0 (default: the frame is needed in one place, like the reference's "
+                         "single framebuffer; RCCL send/recv over rank 0's point-to-point links) or all_gather them to every rank")
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
     ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 no relay, 3 always relay, 4 LDS-staged slab kernel)")
     ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
@@ -292,6 +295,7 @@ def main():
         total_samples = int(t.item())
 
     step_no = [0]
+    root = 0 if (world > 1 and args.collective == "gather") else None
 
     def step(ev_pair=None):
         slot = step_no[0] % nslots
@@ -309,7 +313,7 @@ def main():
         ev_rendered[slot].record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_rendered[slot])
-            frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index)
+            frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index, root=root)
             ev_gathered[slot].record(comm_stream)
         return frame
 
@@ -348,12 +352,13 @@ def main():
     gather_ok = None
     if world > 1:
         torch.cuda.synchronize(dev)
-        gathered_frame = frame.cpu().numpy()
         r.setRowRange(0, -1); r.setRowStripes(1, 0, 1)
         r.setFramebufferExternal(0); r.setFramebufferCompact(False)
         r.render()
         full = r.readPixels()
-        gather_ok = bool(np.array_equal(full.view(np.uint32), gathered_frame.view(np.uint32)))
+        gather_ok = True                                    # ranks that hold no frame (gather to root) have nothing to compare
+        if frame is not None:
+            gather_ok = bool(np.array_equal(full.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
         sharding.apply_plan(r, plan)
         r.setFramebufferExternal(locals_[0].data_ptr()); r.setFramebufferCompact(True)
         t = torch.tensor([1 if gather_ok else 0], dtype=torch.int64, device=dev)
@@ -394,7 +399,7 @@ def main():
                 "samples_per_frame": total_samples,
                 "partition": "single GPU" if world == 1 else f"{args.partition} rows x{world}"
                              + (f" ({args.stripe_rows}-row stripes)" if args.partition == "stripes" else "")
-                             + (" + RCCL all_gather of (grey, alpha) shards" if grey_alpha else " + RCCL all_gather"),
+                             + f" + RCCL {args.collective}" + (" of (grey, alpha) shards" if grey_alpha else "") + (" to rank 0" if root is not None else ""),
                 "kernel": r.last_kernel_name,
                 "voxel_dtype": "u%d" % (8 * b),
                 "clock_ramp_frames": max(args.clock_ramp_frames, 0),
@@ -428,7 +433,7 @@ def main():
         if world > 1:
             result["multi_gpu_frame_bit_exact"] = gather_ok
             result["n_ranks_seen"] = n_ranks_seen
-            result["overlap"] = "all_gather of frame i on a second stream overlaps the kernel of frame i+1"
+            result["overlap"] = f"{args.collective} of frame i on a second stream overlaps the kernel of frame i+1"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
         if world == 1 and not args.no_extras and not args.shard:

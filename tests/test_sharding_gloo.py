@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir, grey_alpha=False):
+def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir, grey_alpha=False, root=None):
     import torch
     import torch.distributed as dist
 
@@ -47,8 +47,10 @@ def _worker(rank, world, port, mode, stripe_rows, W, H, out_dir, grey_alpha=Fals
         local[lr] = full[g]
     if grey_alpha:      # what vr_set_framebuffer_format(VR_FB_GREYALPHA32F) makes the kernel store: (grey, alpha)
         local = np.ascontiguousarray(local[..., [0, 3]])
-    frame = sharding.gather_frame(torch.from_numpy(local), plan)
-    np.save(os.path.join(out_dir, f"frame_{mode}_{rank}.npy"), frame.numpy())
+    frame = sharding.gather_frame(torch.from_numpy(local), plan, root=root)
+    assert (frame is None) == (root is not None and rank != root)
+    if frame is not None:
+        np.save(os.path.join(out_dir, f"frame_{mode}_{rank}.npy"), frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -101,3 +103,18 @@ def test_default_camera_stripes_balance_better_than_blocks():
             assert min(per_rank) == 0
         else:
             assert min(per_rank) >= 96
+
+
+@pytest.mark.parametrize("mode,stripe_rows,grey_alpha,world", [("stripes", 16, True, 2), ("contiguous", 16, False, 3), ("stripes", 8, False, 3)])
+def test_gather_to_root_reassembles_the_frame_on_the_root_only(mode, stripe_rows, grey_alpha, world, tmp_path, oracle):
+    """the default collective of bench.py --gpus N: dist.gather to rank 0 (RCCL send/recv), other ranks get None"""
+    import torch.multiprocessing as mp
+
+    W, H = 40, 53
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, mode, stripe_rows, W, H, str(tmp_path), grey_alpha, 0), nprocs=world, join=True)
+    vol = oracle.gen_noise_ball((24, 20, 28), 1, 77)
+    want, _ = oracle.render(vol, oracle.OracleParams(W, H, alpha_scale=0.05))
+    got = np.load(tmp_path / f"frame_{mode}_0.npy")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert not any((tmp_path / f"frame_{mode}_{k}.npy").exists() for k in range(1, world))

@@ -6,7 +6,8 @@ Pixels are independent, so the frame is split by rows with the volume replicated
                   (balanced: at the default camera only ~75 % of the rows hit the box,
                   SURVEY F7)
 Every rank renders into a COMPACT local target of `local_rows` rows (equal on all ranks,
-padded), one all_gather over RCCL moves the shards, and `assemble` undoes the
+padded), one collective over RCCL moves the shards -- a gather to the root rank (default in
+bench.py: only the root needs the frame) or an all_gather -- and an index_select undoes the
 interleave.  Pure index logic + torch.distributed: runs on gloo/CPU in the tests.
 """
 from __future__ import annotations
@@ -90,8 +91,12 @@ def expand_grey_alpha(ga):
     return ga.index_select(-1, sel)
 
 
-def gather_frame(local, plan: RowPlan, out=None, index=None):
-    """all_gather the compact shards and return the assembled [H, W, 4] frame.
+def gather_frame(local, plan: RowPlan, out=None, index=None, root=None):
+    """gather the compact shards and return the assembled [H, W, 4] frame.
+
+    root = None: all_gather -- every rank ends up with the frame.  root = k: a GATHER to rank k (RCCL
+    implements it as grouped send/recv: the root's point-to-point xGMI links to its peers work
+    concurrently, and 1/world of an all_gather's bytes move); rank k returns the frame, the others None.
 
     local: torch tensor [local_rows, W, C] on this rank's device, C = 4 (RGBA32F) or C = 2
     ((grey, alpha) targets, vr_set_framebuffer_format: half the bytes on the wire; expanded to
@@ -107,7 +112,19 @@ def gather_frame(local, plan: RowPlan, out=None, index=None):
         return expand_grey_alpha(frame) if grey_alpha else frame
     if out is None:
         out = torch.empty((plan.world * plan.local_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend() == "gloo":
+    if root is not None:
+        is_root = plan.rank == root
+        staged = local.is_cuda and dist.get_backend() == "gloo"      # validation hook: ranks sharing one GPU gather through host memory
+        if is_root:
+            dst = torch.empty(out.shape, dtype=out.dtype) if staged else out
+            pieces = list(dst.view((plan.world, plan.local_rows) + tuple(local.shape[1:])).unbind(0))
+            dist.gather(local.cpu() if staged else local, gather_list=pieces, dst=root)
+            if staged:
+                out.copy_(dst)
+        else:
+            dist.gather(local.cpu() if staged else local, dst=root)
+            return None
+    elif local.is_cuda and dist.get_backend() == "gloo":
         # validation hook (several ranks sharing one GPU): stage the gather through host memory
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, local.cpu())
