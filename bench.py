@@ -574,9 +574,11 @@ def extras(args, r, local, stream, b, W, H):
         r.setFramebufferExternal(0); r.setFramebufferCompact(False)
         s = r.countSamples()
         r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
-        for _ in range(5):
-            r.renderAsync()
-        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.08:      # back to sustained clocks (the CPU baseline left the GPU idle)
+            for _ in range(10):
+                r.renderAsync()
+            torch.cuda.synchronize()
         a, c = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(steps):
