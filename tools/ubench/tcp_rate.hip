@@ -11,7 +11,11 @@ __device__ __forceinline__ uint32_t ld(__amdgpu_buffer_rsrc_t rs, uint32_t off)
 {
     if (BYTES == 1) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off, 0, 0);
     if (BYTES == 2) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
-    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+    if (BYTES == 4) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+    if (BYTES == 8) { typedef uint32_t u2 __attribute__((ext_vector_type(2))); const u2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0); return q.x ^ q.y; }
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    return q.x ^ q.y ^ q.z ^ q.w;
 }
 
 // offsets[p][lane]: byte offset of lane's first load; consecutive loads add `stride` (mod table bytes)
@@ -58,15 +62,17 @@ int main()
     add("same, 12-bit packed (odd bytes)", [](int l) { const int row = l / 8, x = (l % 8) * 13 / 10; return (row * 13 / 10 / 4) * 768u + (row * 13 / 10 % 4) * 6u + (x / 4) * 96u + (x % 4) * 3u / 2u; });
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int blocks = 256 * 8, iters = 400;                 // 32 wavefronts per CU
-    printf("%-40s %10s %10s %10s   (cycles per wave-gather per CU at 2.4 GHz; 32 waves/CU)\n", "pattern", "1-byte", "2-byte", "4-byte");
+    printf("%-40s %10s %10s %10s %10s %10s   (cycles per wave-gather per CU at 2.4 GHz; 32 waves/CU)\n", "pattern", "1-byte", "2-byte", "4-byte", "8-byte", "16-byte");
     for (auto &p : pats) {
         hipMemcpy(offs, p.off.data(), 256, hipMemcpyHostToDevice);
-        double cyc[3];
-        for (int w = 0; w < 3; w++) {
+        double cyc[5];
+        for (int w = 0; w < 5; w++) {
             auto launch = [&](int n) {
                 if (w == 0) k<1><<<blocks, 256>>>(table, table_bytes, offs, 0, n, out);
                 if (w == 1) k<2><<<blocks, 256>>>(table, table_bytes, offs, 0, n, out);
                 if (w == 2) k<4><<<blocks, 256>>>(table, table_bytes, offs, 0, n, out);
+                if (w == 3) k<8><<<blocks, 256>>>(table, table_bytes, offs, 0, n, out);
+                if (w == 4) k<16><<<blocks, 256>>>(table, table_bytes, offs, 0, n, out);
             };
             launch(50); launch(iters); hipDeviceSynchronize();
             hipEventRecord(a); launch(iters); hipEventRecord(b); hipEventSynchronize(b);
@@ -74,7 +80,7 @@ int main()
             const double gathers_per_cu = (double)iters * 8.0 * 32.0;
             cyc[w] = ms * 1e-3 * 2.4e9 / gathers_per_cu;
         }
-        printf("%-40s %10.2f %10.2f %10.2f\n", p.name, cyc[0], cyc[1], cyc[2]);
+        printf("%-40s %10.2f %10.2f %10.2f %10.2f %10.2f\n", p.name, cyc[0], cyc[1], cyc[2], cyc[3], cyc[4]);
     }
     return 0;
 }
