@@ -82,12 +82,17 @@ def gather_index(plan: RowPlan):
     return idx
 
 
+_GA_SELECT = {}
+
+
 def expand_grey_alpha(ga):
     """[..., 2] (grey, alpha) -> [..., 4] (grey, grey, grey, alpha): the RGBA32F frame of the
     reference's grey modes, in which r == g == b bit for bit"""
     import torch
 
-    sel = torch.tensor([0, 0, 0, 1], device=ga.device)
+    sel = _GA_SELECT.get(ga.device)
+    if sel is None:             # once per device: building it per frame is a blocking host-to-device copy
+        sel = _GA_SELECT[ga.device] = torch.tensor([0, 0, 0, 1], device=ga.device)
     return ga.index_select(-1, sel)
 
 
