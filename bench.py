@@ -275,6 +275,7 @@ def main():
     r.setFramebufferFormat(R.FB_GREYALPHA32F if grey_alpha else R.FB_RGBA32F)
     locals_ = [torch.zeros((plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)]
     gathered = [torch.empty((world * plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
+    frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
     ev_rendered = [torch.cuda.Event() for _ in range(nslots)]
     ev_gathered = [torch.cuda.Event() for _ in range(nslots)]
     local = locals_[0]
@@ -313,7 +314,8 @@ def main():
         ev_rendered[slot].record(stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_rendered[slot])
-            frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index, root=root)
+            frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index, root=root,
+                                          assembler=r, frame_out=frames[slot])     # one kernel: de-interleave + (grey, alpha) -> RGBA
             ev_gathered[slot].record(comm_stream)
         return frame
 

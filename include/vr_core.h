@@ -113,6 +113,14 @@ int vr_histogram(vr_handle h, float hist256[256]);
    the resident volume with 16-byte loads; *gbps = 1e9 bytes per second.  No reference
    counterpart (the reference reads GL_TIME_ELAPSED only, src/RendererCore.cpp:149-153). */
 int vr_measure_stream_read(vr_handle h, int reps, double *gbps);
+/* Multi-GPU, one process per GPU: on the rank that received the shards, turn the rank-major gather buffer
+   -- n shards of local_rows x fb_w pixels, `channels` floats each (4: RGBA32F, 2: (grey, alpha), see
+   vr_set_framebuffer_format) -- into the fb_w x fb_h RGBA32F frame the GUI blits (src/RendererGUI.cpp:158-162):
+   one kernel on `hip_stream` (0 = the handle's stream) that undoes the row interleave (stripe_rows > 0: cyclic stripes
+   as in vr_set_row_stripes; 0: contiguous blocks as in vr_set_row_range) and expands (grey, alpha).  Both pointers are
+   device memory of this handle's device.  vr_group_render() does the same internally. */
+int vr_assemble_shards(vr_handle h, const void *gathered_device, void *frame_device, int n, int local_rows, int stripe_rows,
+                       int channels, void *hip_stream);
 
 /* ---- PVM / DDS codec (host only, no handle): readPVMvolume of the reference's
         include/ddsbase.h:29-35 (src/ddsbase.cpp:768-858).  Returns a malloc'ed payload of

@@ -243,3 +243,48 @@ def test_reference_datasets_when_supplied(vra, oracle, which, datasize, size):
         p.row_begin, p.row_end = y, y + 1
         oracle.render(vol, p, out=want)
         assert np.array_equal(got[y].view(np.uint32), want[y].view(np.uint32)), f"{which} row {y}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world,channels", [("stripes", 3, 2), ("stripes", 8, 4), ("contiguous", 4, 2), ("contiguous", 3, 4)])
+def test_assemble_shards_matches_the_index_path(vra, oracle, mode, world, channels):
+    """vr_assemble_shards (one kernel on the receiving rank) == sharding's de-interleave + (grey, alpha) expansion,
+    and the shards it is fed are real renders: every rank's compact shard of one frame, gathered by hand."""
+    import torch
+
+    sharding = __import__("importlib").import_module("volume-renderer_amd.sharding")
+    vol = oracle.gen_noise_ball((48, 40, 44), 2, 11)
+    W, H = 160, 100                      # 100 rows: not a multiple of the stripe height or the world size
+    with make(vra, (W, H)) as r:
+        r.setVolume(vol)
+        r.setAlpha(0.03)
+        r.render()
+        full = r.readPixels()
+        R = vra.renderer
+        r.setFramebufferFormat(R.FB_GREYALPHA32F if channels == 2 else R.FB_RGBA32F)
+        r.setFramebufferCompact(True)
+        plans = [sharding.plan_rows(H, world, k, mode, 16) for k in range(world)]
+        gathered = torch.full((world * plans[0].local_rows, W, channels), -7.0, dtype=torch.float32, device="cuda")
+        for k, plan in enumerate(plans):
+            sharding.apply_plan(r, plan)
+            shard = gathered[k * plan.local_rows:(k + 1) * plan.local_rows]
+            r.setFramebufferExternal(shard.data_ptr())
+            r.render()
+        torch.cuda.synchronize()
+        frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            r.assembleShards(gathered.data_ptr(), frame.data_ptr(), world, plans[0].local_rows,
+                             0 if mode == "contiguous" else 16, channels, stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), full.view(np.uint32))
+        # the torch path of sharding.gather_frame's tail gives the same frame
+        idx = torch.as_tensor(sharding.gather_index(plans[0]), device="cuda")
+        ref = gathered[:H] if mode == "contiguous" else gathered.index_select(0, idx)
+        ref = sharding.expand_grey_alpha(ref) if channels == 2 else ref
+        assert torch.equal(ref, frame)
+        # bad geometry is refused, not launched
+        with pytest.raises(Exception):
+            r.assembleShards(gathered.data_ptr(), frame.data_ptr(), 1, 10, 0, channels, 0)
+        r.setFramebufferExternal(0); r.setFramebufferCompact(False); r.setFramebufferFormat(R.FB_RGBA32F)
+        r.setRowRange(0, -1); r.setRowStripes(1, 0, 1)

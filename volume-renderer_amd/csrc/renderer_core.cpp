@@ -364,6 +364,21 @@ void RendererCore::computeHistogram(float out[256])
     }
 }
 
+// the receiving rank's half of the multi-process gather (vr_assemble_shards): de-interleave + (grey, alpha) expansion
+void RendererCore::assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream)
+{
+    requireDevice("assembleShards");
+    if (!gathered || !frame) throw std::invalid_argument("assembleShards: null buffer");
+    if (framebuffer_size[0] <= 0 || framebuffer_size[1] <= 0) throw std::runtime_error("assembleShards: setup() has not run");
+    if (n < 1 || local_rows < 1 || stripe_rows < 0 || (channels != 2 && channels != 4)) throw std::invalid_argument("assembleShards: bad shard geometry");
+    // every frame row must exist in the gather buffer
+    const long long rows_held = stripe_rows == 0 ? (long long)n * local_rows
+                                                 : (long long)(local_rows / stripe_rows) * n * stripe_rows;
+    if (rows_held < framebuffer_size[1] || (stripe_rows > 0 && local_rows % stripe_rows != 0)) throw std::invalid_argument("assembleShards: the shards do not cover the frame");
+    check(launch_assemble(gathered, static_cast<float4 *>(frame), framebuffer_size[0], framebuffer_size[1], n, local_rows, stripe_rows, channels,
+                          hip_stream ? static_cast<hipStream_t>(hip_stream) : stream()), "assemble kernel");
+}
+
 double RendererCore::measureStreamRead(int reps)
 {
     requireDevice("measureStreamRead");

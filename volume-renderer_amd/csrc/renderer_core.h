@@ -91,6 +91,7 @@ public:
     void computeHistogram(float out[256]);
     // best-of-`reps` streaming read of the resident volume; returns GB/s (1e9 bytes per second)
     double measureStreamRead(int reps);
+    void assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream);
     const char *lastKernelName() const { return last_kernel_; }
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     bool hasDevice() const { return device_ >= 0; }

@@ -246,6 +246,12 @@ int vr_measure_stream_read(vr_handle h, int reps, double *gbps)
     });
 }
 
+int vr_assemble_shards(vr_handle h, const void *gathered_device, void *frame_device, int n, int local_rows, int stripe_rows,
+                       int channels, void *hip_stream)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.assembleShards(gathered_device, frame_device, n, local_rows, stripe_rows, channels, hip_stream); });
+}
+
 int vr_set_alpha(vr_handle h, float alpha_scale)
 {
     return guarded(h, [&](vr::RendererCore &c) { c.alpha_scale = alpha_scale; c.setAlpha(); });   // RendererGUI.cpp:336-337

@@ -105,6 +105,7 @@ def load_library() -> C.CDLL:
         "vr_get_dataset_range": (i32, [h, C.POINTER(i32), C.POINTER(i32)]),
         "vr_histogram": (i32, [h, C.POINTER(f32)]),
         "vr_measure_stream_read": (i32, [h, i32, C.POINTER(C.c_double)]),
+        "vr_assemble_shards": (i32, [h, C.c_void_p, C.c_void_p, i32, i32, i32, i32, C.c_void_p]),
         "vr_set_alpha": (i32, [h, f32]),
         "vr_set_mip": (i32, [h, i32]),
         "vr_set_view": (i32, [h, i32, i32]),
@@ -427,6 +428,11 @@ class RendererCore:
         g = C.c_double()
         self._check(self._lib.vr_measure_stream_read(self._h, reps, C.byref(g)))
         return g.value
+
+    def assembleShards(self, gathered_ptr, frame_ptr, n, local_rows, stripe_rows, channels, stream=0):
+        """rank-major gathered shards (device) -> the W x H RGBA32F frame (device): one kernel on `stream`"""
+        self._check(self._lib.vr_assemble_shards(self._h, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr), n, local_rows,
+                                                 stripe_rows, channels, C.c_void_p(stream)))
 
     # -- uniforms
     def setAlpha(self, alpha_scale):

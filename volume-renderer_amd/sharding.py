@@ -96,7 +96,7 @@ def expand_grey_alpha(ga):
     return ga.index_select(-1, sel)
 
 
-def gather_frame(local, plan: RowPlan, out=None, index=None, root=None):
+def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assembler=None, frame_out=None):
     """gather the compact shards and return the assembled [H, W, 4] frame.
 
     root = None: all_gather -- every rank ends up with the frame.  root = k: a GATHER to rank k (RCCL
@@ -107,6 +107,10 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None):
     ((grey, alpha) targets, vr_set_framebuffer_format: half the bytes on the wire; expanded to
     RGBA after the gather).  One collective (RCCL all_gather over xGMI on GPUs) + one
     index_select to undo the interleave.
+
+    assembler = a RendererCore on the same device + frame_out = a preallocated [H, W, 4] float32 tensor: the
+    de-interleave and the (grey, alpha) expansion are done by ONE kernel of the C ABI (vr_assemble_shards) on the
+    current torch stream instead of two index_select launches.
     """
     import torch
     import torch.distributed as dist
@@ -136,6 +140,11 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None):
         out.copy_(host)
     else:
         dist.all_gather_into_tensor(out, local)
+    if assembler is not None and frame_out is not None and out.is_cuda:
+        assembler.assembleShards(out.data_ptr(), frame_out.data_ptr(), plan.world, plan.local_rows,
+                                 0 if plan.mode == "contiguous" else plan.stripe_rows, local.shape[-1],
+                                 torch.cuda.current_stream(out.device).cuda_stream)
+        return frame_out
     if plan.mode == "contiguous":
         frame = out[: plan.img_h]
     else:
