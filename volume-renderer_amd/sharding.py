@@ -83,6 +83,7 @@ def gather_index(plan: RowPlan):
 
 
 _GA_SELECT = {}
+_GATHER_VIEWS = {}
 
 
 def expand_grey_alpha(ga):
@@ -126,7 +127,14 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
         staged = local.is_cuda and dist.get_backend() == "gloo"      # validation hook: ranks sharing one GPU gather through host memory
         if is_root:
             dst = torch.empty(out.shape, dtype=out.dtype) if staged else out
-            pieces = list(dst.view((plan.world, plan.local_rows) + tuple(local.shape[1:])).unbind(0))
+            key = (dst.data_ptr(), tuple(dst.shape), plan.world)
+            pieces = _GATHER_VIEWS.get(key) if not staged else None
+            if pieces is None:              # the per-rank views of a gather buffer are built once, not per frame
+                pieces = list(dst.view((plan.world, plan.local_rows) + tuple(local.shape[1:])).unbind(0))
+                if not staged:
+                    if len(_GATHER_VIEWS) > 16:
+                        _GATHER_VIEWS.clear()
+                    _GATHER_VIEWS[key] = pieces
             dist.gather(local.cpu() if staged else local, gather_list=pieces, dst=root)
             if staged:
                 out.copy_(dst)
