@@ -148,12 +148,14 @@ int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*              
 int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_* (default BRICKED); re-lays the volume out */
 int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
 /* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches
-   of the headline shape with fewer than 256 active 32x16 tiles use the 4-wavefront relay kernel),
-   1 = always the generic line-by-line kernel (cross-check / debugging), 2 = automatic but never
-   the relay kernel, 3 = automatic but always the relay kernel when the shape allows, 4 = the
-   LDS-staged kernel (bricks streamed into LDS by LDS-DMA, vr_slab.hip) wherever it is eligible --
-   bit-identical frames; measured slower than the default kernels on MI355X,
-   kept as an opt-in */
+   of the headline shape with fewer than 256 active 32x16 tiles use the 4-wavefront relay kernel,
+   launches with fewer than 512 the fast kernel's software-pipelined loop),
+   1 = always the generic line-by-line kernel (cross-check / debugging), 2 = the fast kernel with its
+   plain loop: never the relay kernel, never the pipelined loop, 3 = automatic but always the relay kernel
+   when the shape allows, 4 = the LDS-staged kernel (bricks streamed into LDS by LDS-DMA, vr_slab.hip)
+   wherever it is eligible -- bit-identical frames; measured slower than the default kernels on MI355X
+   (DESIGN.md section 6), kept as an opt-in, 5 = the fast kernel with the pipelined loop, never the relay.
+   Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %

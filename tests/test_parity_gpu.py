@@ -75,7 +75,7 @@ def test_cfg0_sphere_default_camera(vra, oracle):
     assert not got[0, 0].any() and not got[255, 255].any()
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["auto", "generic"])
+@pytest.mark.parametrize("variant", [0, 1, 5], ids=["auto", "generic", "pipelined"])
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
 def test_noncubic_spacing_orbits(vra, oracle, dtype, variant):
     """non-cubic dims + anisotropic spacing + odd image + orbit cameras"""
@@ -377,6 +377,11 @@ def test_cfg3_full_size_fast_equals_generic_and_layouts_agree(vra, cfg3):
     r.render()
     assert r.last_kernel_name == "raymarch_generic_kernel"
     generic = r.readPixels()
+    r.setKernelVariant(5)                         # the fast kernel's software-pipelined loop (under-filled launches use it)
+    r.render()
+    assert r.last_kernel_name == "raymarch_fast_kernel"
+    assert np.array_equal(fast.view(np.uint32), r.readPixels().view(np.uint32))
+    assert r.countSamples() == total
     r.setKernelVariant(0)
     assert np.array_equal(fast.view(np.uint32), generic.view(np.uint32))
     r.setLayout(vra.renderer.LAYOUT_LINEAR)       # re-bricking is invisible
@@ -747,13 +752,14 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
         lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
         alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
-        mip = tf = tri = accum = relay = stripes = slab = False
+        mip = tf = tri = accum = relay = stripes = slab = pipe = False
         if extended:
             mode = int(rng.integers(0, 16))
             mip, tf, tri, accum = mode in (1, 8, 13), mode in (2, 8, 14), mode == 3, mode == 4     # 8: MIP through the transfer function
             relay = mode in (5, 6)
             stripes = mode in (7, 15)
             slab = mode in (12, 13, 14, 15)       # the LDS-staged kernel (opt-in variant 4) wherever the trial is eligible for it
+            pipe = mode in (9, 10)                # the fast kernel's software-pipelined loop (variant 5) instead of relay / plain loop
             if rng.random() < 0.2:
                 W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
         tf_lut = None
@@ -786,6 +792,8 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 r.setKernelVariant(3)
             if slab:
                 r.setKernelVariant(4)
+            if pipe:
+                r.setKernelVariant(5)
             rows = None
             if stripes:
                 rows = (4, int(rng.integers(0, 3)), 3)
@@ -896,6 +904,26 @@ def test_relay_kernel_equals_fast_kernel(vra, oracle, variant):
                                             voxel_size=(1.0, 1.0, 1.0) if dims[0] == dims[1] == dims[2] else (1.0, 0.7, 1.9))
                     want, _, want_spp = oracle.render(vol, p, want_spp=True)
                     assert_same(got, want, spp, want_spp, what=f"variant {variant} {dims} {dtype.__name__} layout {layout} {name}")
+
+
+def test_pipelined_loop_full_size_shard(vra, cfg3):
+    """one rank's stripes of the cfg3 frame at N = 4 (335 tiles: under-filled, not sparse): the host picks the fast kernel's
+    pipelined loop; the frame equals the plain loop's bit for bit"""
+    r = cfg3
+    r.setRowStripes(16, 1, 4)
+    r.setKernelVariant(2)
+    r.render()
+    assert r.last_kernel_name == "raymarch_fast_kernel"
+    plain = r.readPixels()
+    spp_plain = r.countSamples()
+    for variant in (0, 5):
+        r.setKernelVariant(variant)
+        r.render()
+        assert r.last_kernel_name == "raymarch_fast_kernel"
+        assert np.array_equal(plain.view(np.uint32), r.readPixels().view(np.uint32))
+        assert r.countSamples() == spp_plain
+    r.setKernelVariant(0)
+    r.setRowStripes(1, 0, 1)
 
 
 def test_relay_kernel_full_size_shard(vra, cfg3):

@@ -614,6 +614,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
     L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
+    L.pipelined = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
         // VoxelAddr: the strides carry minus the part of the in-brick term the split axis repeats
@@ -814,6 +815,12 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     L.sparse_shard = (tile_active_ < 256u) ? 1 : 0;
     if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
+    // In between -- fewer than two tiles per CU, e.g. one rank's shard at N = 3..5 -- the fast kernel runs with its
+    // software-pipelined batch loop (16 gathers per lane in flight): a full launch gains nothing from it (six wavefronts
+    // per SIMD already cover a wavefront's latency, 0.4537 vs 0.4532 ms; the off-axis pose loses 10 % to L1 pressure),
+    // an under-filled one does: 0.161 vs 0.184 ms at N = 4 (335 tiles), 0.142 vs 0.170 at N = 8 (where the relay's 0.108 wins)
+    L.pipelined = (tile_active_ < 512u && force_generic == 0) ? 1 : 0;
+    if (force_generic == 5) { L.pipelined = 1; L.sparse_shard = 0; }   // kernel variant 5: fast kernel, pipelined loop, never the relay
 }
 
 void RendererCore::render()

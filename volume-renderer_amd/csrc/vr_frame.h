@@ -77,6 +77,7 @@ struct LaunchConfig {
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
     int slab_allowed;              // use the LDS-staged kernel where eligible (vr_set_kernel_variant 4; off by default)
+    int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };
 
 }  // namespace vr

@@ -251,7 +251,7 @@ __device__ __forceinline__ bool fast_tile_of_block(unsigned b, unsigned tiles_x,
 // SKIPT: empty-space skipping compiled in (its probe state costs ~18 VGPRs = one workgroup
 // of occupancy per CU, so the headline variant is also built without it).
 // BATCH: samples per gather batch (8: the skip grid's dilation covers exactly that).
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH, bool ATAB, bool PK12>
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool BIG, bool LUT, bool POW2, bool NOCLAMP, int MODE, bool SKIPT, int BATCH, bool ATAB, bool PK12, bool PIPE = false>
 __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams P,
                                                             const VoxelT *__restrict__ vol,
                                                             const float4 *__restrict__ tf,
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                                                             const uint32_t packed12_bytes)
 {
     static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
+    static_assert(!PIPE || (!SKIPT && !BIG), "the pipelined loop issues gathers for lanes without a next batch: bounds-checked buffer loads, no skip branch");
     static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH == 8), "12-bit copy: u16 bricks through the address tables");
     __shared__ float lut[LUT ? (ATAB && BIG ? FAST_BIG_LUT_FLOATS : FAST_LUT_MAX * 2) : 4];   // 32 KiB: 4096 x (c,a) or 256 x (r,g,b,a) + index bytes
     __shared__ uint32_t axis_tab[ATAB ? (BIG ? FAST_AXIS_TAB_BIG_MAX : FAST_AXIS_TAB_MAX) : 1];
@@ -430,7 +431,20 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + (ATAB ? P.nx : 0), *tab_z = axis_tab + (ATAB ? P.nx + P.ny : 0);
         // gathers of one batch: BATCH consecutive samples from the current position;
         // returns true when the batch is skipped (positions still advance, bit-exactly)
-        auto issue = [&](uint32_t (&v)[BATCH], uint32_t &nib) -> bool {   // nib (PK12): bit offset (0 / 4) of sample u in nibble u
+        // PIPE (true software pipelining): the gathers of the next batch are issued by every live lane, also by the
+        // lanes that have no next batch (commit == false: their positions are restored, their loads hit the buffer
+        // bounds check or fetch voxels nobody composites).  A branch around the loads makes the number of loads in
+        // flight at the following s_waitcnt path-dependent, and the compiler then waits for the NEW batch before it
+        // lets the previous one be composited.  With PIPE a wavefront keeps 16 gathers per lane in flight: that
+        // shortens the serial chain of an under-filled launch (one GPU's shard of a multi-GPU frame) and only adds L1
+        // pressure to a full one, so the host picks it per launch (vr_frame.h: LaunchConfig::pipelined).
+        constexpr bool SPEC = PIPE;
+        // The batch arrays hold the loaded voxels in their own width: the zero-extension is then an operation of
+        // consume(), not of issue() -- as a 32-bit value it would be materialised (and the loads waited for) at
+        // the end of the divergent region the gathers are issued in.
+        using RawT = typename std::conditional<BIG, uint32_t, VoxelT>::type;
+        auto issue = [&](RawT (&v)[BATCH], uint32_t &nib, bool commit) -> bool {   // nib (PK12): bit offset (0 / 4) of sample u in nibble u
+            const float Qx0 = Qx, Qy0 = Qy, Qz0 = Qz, qx0 = qx, qy0 = qy, qz0 = qz;
             bool skip = false;
             if (skip_on) {
                 skip = (int)cell_next <= P.skip_thresh;
@@ -469,11 +483,15 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (ATAB && !BIG) {
-                    v[u] = sizeof(VoxelT) == 1 ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[u], 0, 0)
-                                               : (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rs, (int)off[u], 0, 0);
+                    v[u] = sizeof(VoxelT) == 1 ? (RawT)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)off[u], 0, 0)
+                                               : (RawT)__builtin_amdgcn_raw_buffer_load_b16(PK12 ? rs12 : rs, (int)off[u], 0, 0);
                     continue;
                 }
-                v[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
+                v[u] = (RawT)VoxelFetch<VoxelT, BIG>::load(vol, rs, off[u]);
+            }
+            if (SPEC && !commit) {
+                if (POW2) { Qx = Qx0; Qy = Qy0; Qz = Qz0; }
+                else { qx = qx0; qy = qy0; qz = qz0; }
             }
             return false;
         };
@@ -496,7 +514,14 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 da += a * om;
             }
         };
-        auto consume = [&](const uint32_t (&v)[BATCH], bool skipped, uint32_t nib) -> bool {
+        // PK12: the 12 bits of sample u start at bit 0 or 4 of the 16 loaded (nibble u of nib)
+        auto texel_of = [&](RawT raw, uint32_t nib, int u) -> uint32_t {
+            if (!PK12) return (uint32_t)raw;
+            const uint32_t sh = __builtin_amdgcn_ubfe(nib, 4 * u, 4);
+            __builtin_assume(sh <= 4u);
+            return ((uint32_t)raw >> sh) & 0xfffu;
+        };
+        auto consume_live = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib) -> bool {
             if (skipped) { i += BATCH; return false; }   // every sample of the batch adds exactly zero
             float c[BATCH], cg[BATCH], cb[BATCH], a[BATCH];
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
@@ -505,9 +530,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             // latency hides behind the first half's dependent compositing chain
             constexpr int HALF = BATCH / 2;
 #pragma unroll
-            for (int u = 0; u < HALF; u++) classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
+            for (int u = 0; u < HALF; u++) classify(texel_of(v[u], nib, u), c[u], cg[u], cb[u], a[u]);
 #pragma unroll
-            for (int u = HALF; u < BATCH; u++) classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
+            for (int u = HALF; u < BATCH; u++) classify(texel_of(v[u], nib, u), c[u], cg[u], cb[u], a[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (u == BATCH - 1) da_last = da;
@@ -523,6 +548,15 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             }
             return da >= 0.95f;
         };
+        // PIPE: every lane of the wavefront runs the batch (no branch between the gathers and their use, see
+        // issue()); the lanes that are not `live` get their state back.
+        auto consume = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib, bool live) -> bool {
+            const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
+            const int i0 = i;
+            bool term = consume_live(v, skipped, nib);
+            if (SPEC && !live) { drgb = drgb0; dg = dg0; db = db0; da = da0; i = i0; term = false; }
+            return term;
+        };
 
         bool done = false;
         // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
@@ -532,31 +566,42 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         // their rays cross the same voxel rows / bricks at the same time, so a cache line
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
-            uint32_t va[BATCH], vb[BATCH];
+            RawT va[BATCH], vb[BATCH];
             uint32_t nib_a = 0, nib_b = 0;
             bool skip_a = false, skip_b = false;
             int b = 0;
             bool fin = nb == 0;
             if (!fin) {
                 if (skip_on) cell_next = probe(0);
-                skip_a = issue(va, nib_a);
+                skip_a = issue(va, nib_a, true);
             }
             // lockstep: one plain barrier per 16 samples; every 4th doubles as the vote "all rays finished"
             // (__syncthreads_and is three barriers and a cross-lane reduction: 0.464 -> 0.458 ms on cfg3)
             for (unsigned it = 0;; it++) {
                 if ((it & 3u) == 0u) { if (__syncthreads_and(fin ? 1 : 0)) break; }
                 else __syncthreads();
+                if (SPEC) {
+                    // straight-line body: the compiler's s_waitcnt sees exactly eight gathers issued behind the
+                    // eight it is about to use, on every path (ISA: vmcnt(15) ... vmcnt(8))
+                    if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) continue;      // nothing left in this wavefront
+                    bool live = !fin;
+                    skip_b = issue(vb, nib_b, live && b + 1 < nb);
+                    if (consume(va, skip_a, nib_a, live)) { done = true; fin = true; }
+                    else if (live && ++b >= nb) fin = true;
+                    live = !fin;
+                    skip_a = issue(va, nib_a, live && b + 1 < nb);
+                    if (consume(vb, skip_b, nib_b, live)) { done = true; fin = true; }
+                    else if (live && ++b >= nb) fin = true;
+                    continue;
+                }
                 if (!fin) {
-                    if (b + 1 < nb) skip_b = issue(vb, nib_b);
-                    if (consume(va, skip_a, nib_a)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_b = issue(vb, nib_b, true);
+                    if (consume(va, skip_a, nib_a, true)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
-#if defined(VR_EXPERIMENTS) && defined(VR_X_LOCKSTEP8)
-                __syncthreads();
-#endif
                 if (!fin) {
-                    if (b + 1 < nb) skip_a = issue(va, nib_a);
-                    if (consume(vb, skip_b, nib_b)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_a = issue(va, nib_a, true);
+                    if (consume(vb, skip_b, nib_b, true)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
             }
@@ -1373,7 +1418,16 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH, ATAB, PK12>), dim3(blocks),
+    if constexpr (!SKIPT && !BIG && ATAB) {
+        if (L.pipelined) {          // under-filled launch: 16 gathers per lane in flight shorten the serial chain
+            hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH, ATAB, PK12, true>), dim3(blocks),
+                               dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
+                               g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes,
+                               PK12 ? L.packed12 : nullptr, PK12 ? L.packed12_bytes : 0u);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH, ATAB, PK12, false>), dim3(blocks),
                        dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
                        g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes,
                        PK12 ? L.packed12 : nullptr, PK12 ? L.packed12_bytes : 0u);
