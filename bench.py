@@ -619,6 +619,7 @@ def extras(args, r, local, stream, b, W, H):
     if args.filter == "nearest":
         r.setFilter(R.FILTER_TRILINEAR)
         timed("trilinear_deep", steps=10)
+        out["trilinear_deep"]["apron_copy_bytes"] = r.trilinearCopyBytes()      # TRILINEAR's own copy of the volume (vr_set_trilinear_copy)
         r.setFilter(R.FILTER_NEAREST)
     if args.pose == "default":
         r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)

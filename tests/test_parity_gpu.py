@@ -986,3 +986,41 @@ def test_relay_kernel_modes_and_views(vra, oracle, dtype, mode):
                                             is_mip=int(mip), view_top=int(top), view_bottom=int(bottom), tf_rgba=tf_lut)
                     want, _, want_spp = oracle.render(vol, p, want_spp=True)
                     assert_same(got, want, spp, want_spp, what=f"relay {mode} {dims} {np.dtype(dtype).name} layout {layout} {name}")
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
+def test_trilinear_apron_copy_is_invisible(vra, oracle, dtype):
+    """TRILINEAR on the bricked layout gathers from the apron copy (every 4^3 brick stored as 5x4x4): frames equal the
+    ones without it and the oracle's, bit for bit -- dims that are not multiples of 4, rays through every face of the
+    box (clamped taps at the faces), composite and MIP"""
+    R = vra.renderer
+    rng = np.random.default_rng(31)
+    for dims, spacing, size in (((37, 22, 41), (1.0, 1.3, 0.8), (150, 110)), ((64, 64, 64), (1.0, 1.0, 1.0), (128, 96)), ((5, 3, 2), (1.0, 1.0, 1.0), (64, 48))):
+        vol = rand_volume(rng, dims, dtype, smooth=True)
+        vmax = 255 if dtype == np.uint8 else 4095
+        lo, hi = vmax // 10, vmax - vmax // 8
+        with make_renderer(vra, size) as r:
+            r.setQuirks(0)
+            r.setVolume(vol, spacing)
+            r.setWindow(lo, hi)
+            r.setFilter(R.FILTER_TRILINEAR)
+            for mip, alpha in ((False, 0.05), (True, 0.5), (False, 1.0)):
+                r.setAlpha(alpha); r.setMIP(mip)
+                for name, block in orbit_blocks(oracle):
+                    r.setCameraBlock(block)
+                    r.setTrilinearCopy(True)
+                    r.render()
+                    assert r.last_kernel_name == "raymarch_tri_kernel"
+                    assert r.trilinearCopyBytes() > 0
+                    with_copy = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    r.setTrilinearCopy(False)
+                    r.render()
+                    assert r.last_kernel_name == "raymarch_tri_kernel" and r.trilinearCopyBytes() == 0
+                    assert np.array_equal(with_copy.view(np.uint32), r.readPixels().view(np.uint32)), (dims, name, mip)
+                    p = oracle.OracleParams(size[0], size[1], cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi,
+                                            is_mip=int(mip), filter=1)
+                    want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                    assert_same(with_copy, want, spp, want_spp, what=f"apron {dims} {name} mip={mip}")
+            r.setLayout(R.LAYOUT_LINEAR); r.setTrilinearCopy(True); r.render()      # the linear layout has no apron copy
+            assert r.trilinearCopyBytes() == 0

@@ -94,6 +94,7 @@ public:
     void assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream);
     const char *lastKernelName() const { return last_kernel_; }
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
+    size_t lastApronBytes() const { return last_apron_bytes_; }
     bool hasDevice() const { return device_ >= 0; }
 
     int filter = 0, accum = 0, skip_empty = 0;
@@ -101,6 +102,7 @@ public:
     uint32_t quirks = 2u;   // VR_QUIRK_DEFAULT
     int force_generic = 0;
     int pack12 = 1;                          // 1: keep a 12-bit packed copy for the fast kernel when the data allow (vr_set_pack12)
+    int tri_apron = 1;                       // 1: keep an apron copy (5x4x4-stored bricks) for the TRILINEAR kernel (vr_set_trilinear_copy)
     int tile_order = 1;      // 1: longest-first tile schedule, 0: arithmetic order
     std::string last_error;
 
@@ -146,6 +148,10 @@ private:
     bool vol12_failed_ = false;              // allocation of the packed copy failed for this volume: do not retry
     size_t last_packed12_bytes_ = 0;         // packed copy used by the last launch (0 = none)
     void refreshPacked12(const FrameParams &P, LaunchConfig &L);
+    void *d_apron_ = nullptr;                // TRILINEAR's apron copy of the volume (vr_frame.h: apron_voxels)
+    size_t apron_bytes_ = 0, last_apron_bytes_ = 0;
+    bool apron_failed_ = false;
+    void refreshApron(const FrameParams &P, LaunchConfig &L);
     size_t skip_grid_cells_ = 0;
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)

@@ -333,6 +333,19 @@ int vr_set_pack12(vr_handle h, int enable)
     return guarded(h, [&](vr::RendererCore &c) { c.pack12 = enable != 0; });
 }
 
+int vr_set_trilinear_copy(vr_handle h, int enable)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.tri_apron = enable != 0; });
+}
+
+int vr_get_trilinear_copy_bytes(vr_handle h, size_t *bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        if (!bytes) throw std::invalid_argument("vr_get_trilinear_copy_bytes: null result");
+        *bytes = c.lastApronBytes();
+    });
+}
+
 int vr_get_pack12_bytes(vr_handle h, size_t *bytes)
 {
     return guarded(h, [&](vr::RendererCore &c) {

@@ -21,6 +21,13 @@ constexpr int BRICK_LX = VR_BRICK_LX, BRICK_LY = VR_BRICK_LY, BRICK_LZ = VR_BRIC
 constexpr int BRICK_X = 1 << BRICK_LX, BRICK_Y = 1 << BRICK_LY, BRICK_Z = 1 << BRICK_LZ;
 static_assert(BRICK_LX + BRICK_LY + BRICK_LZ == 6 && BRICK_LX >= 1, "bricks hold 64 voxels");
 
+// TRILINEAR's apron copy (vr_device.h: build_axis_tables_apron): 4x4x4 bricks stored as 5x4x4
+constexpr uint32_t APRON_BRICK_VOXELS = 80;
+constexpr uint64_t apron_voxels(int nx, int ny, int nz)
+{
+    return (uint64_t)((nx + 3) >> 2) * (uint64_t)((ny + 3) >> 2) * (uint64_t)((nz + 3) >> 2) * APRON_BRICK_VOXELS;
+}
+
 // widest window (in voxel values) the specialised kernels classify through LDS with a transfer
 // function: one index byte per value behind the 256-entry RGBA table in a 32 KiB array
 constexpr int FAST_TF_WINDOW_MAX = 4096 * 8 - 256 * 16;
@@ -77,6 +84,8 @@ struct LaunchConfig {
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
     int slab_allowed;              // use the LDS-staged kernel where eligible (vr_set_kernel_variant 4; off by default)
+    const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
+    uint32_t apron_bytes;
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };
 

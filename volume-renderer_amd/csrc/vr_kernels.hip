@@ -656,7 +656,8 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
 // Every sample goes through the generic kernel's operations in the generic kernel's order.
 constexpr int TRI_BATCH = 2;
 
-template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool POW2, int MIPM>
+// APRON: `vol` is the apron copy (vr_device.h: build_axis_tables_apron) -- x neighbours are always one load.
+template <typename VoxelT, int LAYOUT, int DIVTC, int VIEW, bool POW2, int MIPM, bool APRON = false>
 __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, const VoxelT *__restrict__ vol,
                                                            const uint32_t vol_bytes, float4 *__restrict__ fb,
                                                            uint32_t *__restrict__ spp,
@@ -685,7 +686,8 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         hit = intersect_ray_aabb(P, ray, t_min, t_max);
     }
     if (__syncthreads_or(hit ? 1 : 0)) {
-        build_axis_tables<VoxelT, LAYOUT, false>(P, axis_tab, 512);
+        if (APRON) build_axis_tables_apron<VoxelT>(P, axis_tab, 512);
+        else build_axis_tables<VoxelT, LAYOUT, false>(P, axis_tab, 512);
         __syncthreads();
     }
     const uint32_t *tab_x = axis_tab, *tab_y = axis_tab + P.nx, *tab_z = axis_tab + P.nx + P.ny;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         const int j0 = med3_i32(iv, 0, nym1), j1 = med3_i32(iv + 1, 0, nym1);
         const int k0 = med3_i32(iw, 0, nzm1), k1 = med3_i32(iw + 1, 0, nzm1);
         const uint32_t x0 = tab_x[i0], x1 = tab_x[i1], y0 = tab_y[j0], y1 = tab_y[j1], z0 = tab_z[k0], z1 = tab_z[k1];
-        pair = x1 == x0 + (uint32_t)sizeof(VoxelT);
+        pair = APRON ? i1 != i0 : x1 == x0 + (uint32_t)sizeof(VoxelT);      // APRON: only the clamped taps at the volume's faces are not a pair
         off[0] = x0 + y0 + z0; off[1] = x0 + y1 + z0; off[2] = x0 + y0 + z1; off[3] = x0 + y1 + z1;
         off[4] = x1 + y0 + z0; off[5] = x1 + y1 + z0; off[6] = x1 + y0 + z1; off[7] = x1 + y1 + z1;
     };
@@ -1577,7 +1579,12 @@ static hipError_t dispatch_tri(const FrameParams &P, const LaunchConfig &L, cons
     const dim3 grid(L.tile_table_blocks), block(512);
 #define VR_TRI(TC, VW, P2, MP)                                                                                   \
     do {                                                                                                         \
-        hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP>), grid, block, 0, st, P,          \
+        if (LAYOUT == 1 && L.apron != nullptr) {                                                                 \
+            hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP, LAYOUT == 1>), grid, block, 0, st, P, \
+                               (const VoxelT *)L.apron, L.apron_bytes, fb, spp, L.tile_table);                    \
+            return hipGetLastError();                                                                            \
+        }                                                                                                        \
+        hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP, false>), grid, block, 0, st, P,   \
                            (const VoxelT *)vol, (uint32_t)L.vol_bytes32, fb, spp, L.tile_table);                  \
         return hipGetLastError();                                                                                \
     } while (0)
@@ -1768,6 +1775,33 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
 
 // 12-bit packed copy of a u16 volume whose voxels are all <= 4095: voxel with storage index s
 // occupies bits [12s, 12s + 12) of a little-endian bit stream (8 voxels -> 3 dwords).  Any
+// the resident volume (linear or cube-bricked) -> TRILINEAR's apron copy (vr_device.h: build_axis_tables_apron)
+template <typename VoxelT>
+__global__ __launch_bounds__(256) void relayout_apron_kernel(const VoxelT *__restrict__ vol, VoxelT *__restrict__ out, uint32_t nx, uint32_t ny,
+                                                             uint32_t nz, int layout, uint32_t bnx, uint32_t bny, uint64_t total)
+{
+    const uint32_t abx = (nx + 3u) >> 2, aby = (ny + 3u) >> 2;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t brick = s / APRON_BRICK_VOXELS;
+        const uint32_t r = (uint32_t)(s % APRON_BRICK_VOXELS), xl = r % 5u, yl = (r / 5u) & 3u, zl = r / 20u;
+        const uint32_t bx = (uint32_t)(brick % abx), by = (uint32_t)((brick / abx) % aby), bz = (uint32_t)(brick / ((uint64_t)abx * aby));
+        const uint32_t i = min(4u * bx + xl, nx - 1u), j = min(4u * by + yl, ny - 1u), k = min(4u * bz + zl, nz - 1u);   // edge voxels repeat
+        out[s] = vol[storage_index(layout, i, j, k, nx, ny, bnx, bny)];
+    }
+}
+
+hipError_t launch_relayout_apron(const void *vol, void *out, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
+                                 uint32_t bnx, uint32_t bny, hipStream_t st)
+{
+    const uint64_t total = apron_voxels((int)nx, (int)ny, (int)nz);
+    const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 256u * 64u);
+    if (bytes_per_voxel == 1)
+        hipLaunchKernelGGL(relayout_apron_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t *)vol, (uint8_t *)out, nx, ny, nz, layout, bnx, bny, total);
+    else
+        hipLaunchKernelGGL(relayout_apron_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)vol, (uint16_t *)out, nx, ny, nz, layout, bnx, bny, total);
+    return hipGetLastError();
+}
+
 // storage order works; the fast kernel reads the bricked one (PK12).
 __global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ dst, uint64_t ngroups)
 {

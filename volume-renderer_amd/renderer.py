@@ -119,6 +119,8 @@ def load_library() -> C.CDLL:
         "vr_set_kernel_variant": (i32, [h, i32]),
         "vr_set_pack12": (i32, [h, i32]),
         "vr_get_pack12_bytes": (i32, [h, C.POINTER(C.c_size_t)]),
+        "vr_set_trilinear_copy": (i32, [h, i32]),
+        "vr_get_trilinear_copy_bytes": (i32, [h, C.POINTER(C.c_size_t)]),
         "vr_set_transfer_function": (i32, [h, C.POINTER(C.c_int32), C.POINTER(f32), i32]),
         "vr_get_transfer_lut": (i32, [h, C.POINTER(f32)]),
         "vr_set_row_range": (i32, [h, i32, i32]),
@@ -479,6 +481,15 @@ class RendererCore:
         """bytes of the 12-bit packed copy the last launch gathered from (0 = none)"""
         n = C.c_size_t()
         self._check(self._lib.vr_get_pack12_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def setTrilinearCopy(self, on):
+        self._check(self._lib.vr_set_trilinear_copy(self._h, int(bool(on))))
+
+    def trilinearCopyBytes(self) -> int:
+        """bytes of the apron copy the last TRILINEAR launch gathered from (0 = none)"""
+        n = C.c_size_t()
+        self._check(self._lib.vr_get_trilinear_copy_bytes(self._h, C.byref(n)))
         return int(n.value)
 
     def setTransferFunction(self, iso=None, rgba=None):
