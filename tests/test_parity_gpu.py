@@ -922,6 +922,15 @@ def test_pipelined_loop_full_size_shard(vra, cfg3):
         assert r.last_kernel_name == "raymarch_fast_kernel"
         assert np.array_equal(plain.view(np.uint32), r.readPixels().view(np.uint32))
         assert r.countSamples() == spp_plain
+    # an oblique view keeps the relay kernel up to 512 tiles (its tiles are L1-bound chains: the pipelined loop would lose)
+    r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+    r.setKernelVariant(2); r.render()
+    assert r.last_kernel_name == "raymarch_fast_kernel"
+    oblique_plain = r.readPixels()
+    r.setKernelVariant(0); r.render()
+    assert r.last_kernel_name == "raymarch_relay_kernel"
+    assert np.array_equal(oblique_plain.view(np.uint32), r.readPixels().view(np.uint32))
+    r.resetCamera()
     r.setKernelVariant(0)
     r.setRowStripes(1, 0, 1)
 

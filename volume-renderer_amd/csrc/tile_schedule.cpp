@@ -46,6 +46,24 @@ int globalRow(const FrameParams &P, int ly)
 
 }  // namespace
 
+double viewAxisAlignment(const FrameParams &P)
+{
+    const float *c = P.cam;
+    // central ray: direction (0, 0, -view_plane_dist) through the view matrix, then box units -> voxel units per axis
+    // (a permutation of the axes -- the rotated views -- does not change the measure)
+    double m[3], n2 = 0.0, big = 0.0;
+    const bool swz = P.view_top == 1 || P.view_bottom == 1;          // box y / z carry voxel z / y in the rotated views
+    const double vdim[3] = {(double)P.nx, swz ? (double)P.nz : (double)P.ny, swz ? (double)P.ny : (double)P.nz};
+    for (int r = 0; r < 3; r++) {
+        m[r] = -(double)c[8 + r] * (double)c[20];
+        const double ext = (double)P.ext[r] > 0.0 ? (double)P.ext[r] : 1.0;
+        m[r] *= vdim[r] / ext;
+        n2 += m[r] * m[r];
+        big = std::max(big, std::fabs(m[r]));
+    }
+    return n2 > 0.0 ? big / std::sqrt(n2) : 1.0;
+}
+
 uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
 {
     uint64_t hsh = 1469598103934665603ull;

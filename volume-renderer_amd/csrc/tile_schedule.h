@@ -23,6 +23,10 @@ constexpr uint32_t kTilePadding = 0xffffffffu;
 // returns the number of tiles with a non-zero work estimate
 unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table);
 
+// how close the view is to a volume axis: |largest component| of the central ray's direction in voxel units, 1 = along
+// an axis, 0.58 = along the space diagonal.  Launch heuristics only (RendererCore::prepareLaunch).
+double viewAxisAlignment(const FrameParams &P);
+
 // cheap fingerprint of everything the schedule depends on; with_camera = false: of everything
 // that decides WHICH tiles exist (image, shard, volume box) -- the camera only decides their order
 uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera = true);
