@@ -844,22 +844,19 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
-    // 8 wavefronts per active 32x16 tile against 256 CUs x 32 wave slots: a launch far from
-    // filling the chip is latency-bound per ray -> relay kernel.  Measured on cfg3 shards (both
-    // kernels with address tables + packed copy): fast / relay = 0.30 / 0.36 ms at N = 2 (685
-    // active tiles), 0.19 / 0.20 at N = 4 (342), 0.17 / 0.11 at N = 8 (171), 0.51 / 0.67 full frame
-    // Oblique views (central ray more than ~23 degrees off every volume axis) keep the relay up to 512 tiles and never
-    // use the pipelined loop: there a tile's chain is bound by the L1 (18 lines per gather), more loads in flight only
-    // thrash it (off-axis pose, N = 4: relay 1.00 / plain 1.15 / pipelined 1.20 ms; N = 2: plain 1.25 / relay 1.62)
+    // Kernel choice per launch (all bit-identical; measured on cfg3 after the checked-head fix, tools/pose_sweep.py and
+    // tools/shard_ms.py; `aligned` = central ray within ~23 degrees of a volume axis):
+    //   * relay kernel (4 wavefronts per 8x8 tile) for launches far from filling the chip -- fewer than 256 active
+    //     32x16 tiles when the view is aligned (N = 8 shard: 0.107 vs 0.142 ms), fewer than 1024 when it is oblique
+    //     (its rays are longer chains with more L1 misses per step: N = 2 shards 0.31-0.36 vs 0.36-0.47 ms);
+    //   * otherwise the fast kernel, with its software-pipelined batch loop unless the opacity scale says rays end
+    //     early (alpha >= 0.5: the speculative batch is wasted, 0.198 vs 0.189 ms): equal at the default pose
+    //     (0.454 ms), 3-14 % faster over oblique poses, 12 % at an N = 4 shard (0.163 vs 0.185 ms).
     const bool aligned = viewAxisAlignment(P) >= 0.92;
-    L.sparse_shard = (tile_active_ < (aligned ? 256u : 512u)) ? 1 : 0;
+    L.sparse_shard = (tile_active_ < (aligned ? 256u : 1024u)) ? 1 : 0;
     if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
-    // In between -- fewer than two tiles per CU, e.g. one rank's shard at N = 3..5 -- the fast kernel runs with its
-    // software-pipelined batch loop (16 gathers per lane in flight): a full launch gains nothing from it (six wavefronts
-    // per SIMD already cover a wavefront's latency, 0.4537 vs 0.4532 ms; the off-axis pose loses 10 % to L1 pressure),
-    // an under-filled one does: 0.161 vs 0.184 ms at N = 4 (335 tiles), 0.142 vs 0.170 at N = 8 (where the relay's 0.108 wins)
-    L.pipelined = (aligned && tile_active_ < 512u && force_generic == 0) ? 1 : 0;
+    L.pipelined = (force_generic == 0 && P.alpha_scale < 0.5f) ? 1 : 0;
     if (force_generic == 5) { L.pipelined = 1; L.sparse_shard = 0; }   // kernel variant 5: fast kernel, pipelined loop, never the relay
 }
 

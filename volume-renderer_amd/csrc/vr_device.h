@@ -322,6 +322,38 @@ __device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx
     return k_safe;
 }
 
+// The first sample of a ray sits EPSILON * |dir| = 1e-6 * |dir_a| inside the face it entered through -- closer to it
+// than the prefix's fixed margin (16 ulps of the half extent) whenever |dir_a| < ~0.48, i.e. for about half of the rays
+// of an oblique view: safe_prefix_length() then refuses the whole ray and it marches sample by sample through the
+// checked loop.  head_steps() = how many leading samples have to take the checked loop so that the position is inside
+// the shrunk box (normally 1: one step is ~1e-3 * |dir_a|); the safe prefix is then computed from the sample after them.
+// 0 = the ray starts inside already, or it never gets there within HEAD_STEPS_MAX samples (then nothing changes).
+constexpr int HEAD_STEPS_MAX = 16;
+__device__ __forceinline__ int head_steps(const FrameParams &P, float qx, float qy, float qz, float dsx, float dsy, float dsz)
+{
+    const float hm = fmaxf(fmaxf(P.half[0], P.half[1]), P.half[2]);
+    const float B = hm + fmaxf(fmaxf(fabsf(dsx), fabsf(dsy)), fabsf(dsz)) + 1e-3f;
+    const float e = B * 1.1920929e-7f, base = hm * 9.5367432e-7f;       // as in safe_prefix_length
+    const float q[3] = { qx, qy, qz }, ds[3] = { dsx, dsy, dsz };
+    float need = 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lim = P.half[a] - base;
+        if (q[a] > lim) {                       // above the shrunk box: must move down by more than the error grows
+            const float v = ds[a] + e;
+            ok = ok && v < 0.0f;
+            need = fmaxf(need, (lim - q[a]) / v);
+        } else if (q[a] < -lim) {
+            const float v = ds[a] - e;
+            ok = ok && v > 0.0f;
+            need = fmaxf(need, (-lim - q[a]) / v);
+        }
+    }
+    if (!ok || !(need >= 0.0f) || need > (float)(HEAD_STEPS_MAX - 2)) return 0;
+    return need > 0.0f ? (int)need + 2 : 0;     // + 1 rounds up, + 1 more sample of slack
+}
+
 // Size for the buffer descriptor of kernels that fetch an x-neighbour pair with one load: a
 // pair load on the LAST voxel of the buffer reaches 2 (u16) / 1 (u8) bytes past it, and a raw
 // buffer load that is partly out of range returns 0 for ALL of it.  The allocation carries

@@ -347,7 +347,12 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
         const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
 
-        // ---- safe prefix length
+        // ---- checked head (vr_device.h: head_steps): the samples before the safe prefix can start.  Their positions are
+        //      stepped here (the shader's additions); they are sampled through the checked loop further down
+        const float hqx = qx, hqy = qy, hqz = qz;
+        const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+        for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
+        // ---- safe prefix length (samples head .. head + k_safe - 1)
         const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
 
         // texcoord -> voxel index of a position; valid (unclamped) inside the prefix
@@ -559,9 +564,37 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         };
 
         bool done = false;
+        // one iteration of the shader's loop at position (x, y, z), literally (dest.a > 0.99 of :134 is implied by the
+        // dest.a >= 0.95 test of the next iteration and changes nothing); true = the loop ends here
+        auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
+            const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
+            const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
+            const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
+            const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
+            float c, cg = 0.0f, cb = 0.0f, a;
+            classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, cg, cb, a);
+            accumulate(c, cg, cb, a);
+            x += stx; y += sty; z += stz;
+            return false;
+        };
+        // ---- checked head: samples 0 .. head - 1
+        if (head > 0) {
+            float x = hqx, y = hqy, z = hqz;
+            for (int h = 0; h < head && !done; h++) {
+                if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) done = true;     // the ray ends inside its head
+                else i++;
+            }
+        }
         // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
         //      while the current batch is composited
-        const int nb = k_safe / BATCH;
+        const int nb = done ? 0 : k_safe / BATCH;
         // The 8 wavefronts of a workgroup advance in lockstep (one barrier per two batches):
         // their rays cross the same voxel rows / bricks at the same time, so a cache line
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
@@ -613,28 +646,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz;
             tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
         }
-        // ---- checked tail: the shader's loop, literally (dest.a > 0.99 of :134 is implied
-        //      by the dest.a >= 0.95 test of the next iteration and changes nothing)
+        // ---- checked tail: the shader's loop
         if (hit && !done) {
-            const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
-            for (; i < P.max_steps; i++) {
-                const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-                const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-                float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
-                uz = 1.0f - uz;
-                float tcx = ux, tcy = uy, tcz = uz;
-                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
-                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-                if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f)
-                    break;
-                const int vi = min((int)(tcx * P.fdim[0]), nxm1);
-                const int vj = min((int)(tcy * P.fdim[1]), nym1);
-                const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-                float c, cg = 0.0f, cb = 0.0f, a;
-                classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, cg, cb, a);
-                accumulate(c, cg, cb, a);
-                qx += tsx; qy += tsy; qz += tsz;
-            }
+            for (; i < P.max_steps; i++)
+                if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
         }
         fetches = (uint32_t)i;
     }
@@ -697,6 +712,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
     float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
     const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    // checked head (vr_device.h: head_steps): positions stepped here, sampled through the checked loop below
+    const float hqx = qx, hqy = qy, hqz = qz;
+    const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
     const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
 
@@ -836,7 +855,34 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     };
 
     bool done = false;
-    const int nb = k_safe / TRI_BATCH;
+    // one iteration of the shader's loop at (x, y, z), literally; true = the loop ends here
+    auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
+        const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+        const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+        float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+        uz = 1.0f - uz;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+        if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
+        uint32_t off[8], tv[8];
+        float ax, ay, az, c, a;
+        bool pair;
+        taps_of(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], off, ax, ay, az, pair);
+        load_taps(off, pair, 0, tv);
+        shade(tv, pair, ax, ay, az, c, a);
+        accumulate(c, a);
+        x += stx; y += sty; z += stz;
+        return false;
+    };
+    if (head > 0) {                                          // checked head: samples 0 .. head - 1
+        float x = hqx, y = hqy, z = hqz;
+        for (int h = 0; h < head && !done; h++) {
+            if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) done = true;
+            else i++;
+        }
+    }
+    const int nb = done ? 0 : k_safe / TRI_BATCH;
     {
         uint32_t va[TRI_BATCH * 8], vb[TRI_BATCH * 8];
         float wa[TRI_BATCH * 3], wb[TRI_BATCH * 3];
@@ -863,26 +909,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz;           // exact: S is a power of two
         tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
     }
-    // ---- checked tail: the shader's loop, literally
+    // ---- checked tail: the shader's loop
     if (hit && !done) {
-        for (; i < P.max_steps; i++) {
-            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
-            float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
-            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
-            uint32_t off[8], tv[8];
-            float ax, ay, az, c, a;
-            bool pair;
-            taps_of(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], off, ax, ay, az, pair);
-            load_taps(off, pair, 0, tv);
-            shade(tv, pair, ax, ay, az, c, a);
-            accumulate(c, a);
-            qx += tsx; qy += tsy; qz += tsz;
-        }
+        for (; i < P.max_steps; i++)
+            if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
@@ -1003,6 +1033,11 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
     float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
     const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    // checked head (vr_device.h: head_steps): every wavefront steps the positions identically; wavefront 0 samples them
+    // through the checked loop before its first batch (it is the one that reads state slot 0)
+    const float hqx = qx, hqy = qy, hqz = qz;
+    const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
     const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     const int nb = k_safe / RELAY_BATCH;                 // batches of THIS ray
     int nbmax = nb;                                      // batches of the tile (same in all 4 wavefronts)
@@ -1171,6 +1206,31 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     };
 
     {
+        if (w == 0 && head > 0) {                            // samples 0 .. head - 1, literally, into state slot 0
+            float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f, x = hqx, y = hqy, z = hqz;
+            int i = 0;
+            for (int h = 0; h < head && i < P.max_steps; h++) {
+                const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+                const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+                float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+                uz = 1.0f - uz;
+                float tcx = ux, tcy = uy, tcz = uz;
+                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+                if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
+                const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
+                const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
+                const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
+                float c, cg = 0.0f, cb = 0.0f, a;
+                classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, cg, cb, a);
+                accumulate(drgb, dg, db, da, c, cg, cb, a);
+                x += dsx; y += dsy; z += dsz;
+                i++;
+            }
+            rs.rgb[0][lane] = drgb; rs.a[0][lane] = da; rs.i[0][lane] = i;
+            if (MODE >= 2) { rs.g[0][lane] = dg; rs.b[0][lane] = db; }
+            da_seen = da;
+        }
         uint32_t va[RELAY_BATCH], vb[RELAY_BATCH];
         uint32_t nib_a = 0, nib_b = 0;
         bool ok_a = false, ok_b = false;
