@@ -228,6 +228,10 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
     float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
     const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    // checked head (vr_device.h: head_steps): positions stepped here, sampled through the checked loop below
+    const float hqx = qx, hqy = qy, hqz = qz;
+    const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
     const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     const int nb = k_safe / BATCH;                                      // phases of this ray's prefix
 
@@ -466,6 +470,33 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         }
     };
     int i = 0;
+    // one iteration of the shader's loop at (x, y, z), literally; true = the loop ends here
+    auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
+        const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+        const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+        float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+        uz = 1.0f - uz;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+        if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
+        const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
+        const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
+        const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
+        float c, cg = 0.0f, cb = 0.0f, a;
+        classify((uint32_t)vol[VoxelAddr<1, true>::at(P, vi, vj, vk)], c, cg, cb, a);
+        accumulate(c, cg, cb, a);
+        x += stx; y += sty; z += stz;
+        return false;
+    };
+    bool head_ended = false;
+    if (head > 0) {                                                      // samples 0 .. head - 1
+        float x = hqx, y = hqy, z = hqz;
+        for (int h = 0; h < head && !head_ended; h++) {
+            if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) head_ended = true;
+            else i++;
+        }
+    }
     // compositing of one phase; returns true when the ray terminated (batch early-termination, see the fast kernel)
     auto consume = [&](const uint32_t (&v)[BATCH], uint32_t nib, bool raw) -> bool {
         float c[BATCH], cg[BATCH], cb[BATCH], a[BATCH];
@@ -496,8 +527,8 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     // of phase p-1" before their slots are overwritten, and "the pieces each wavefront waited for have landed"
     // before anybody reads them); every 8th phase the barrier doubles as the vote "all rays finished" (a ray
     // ends early by early ray termination only; the longest prefix, nbmax phases, bounds the loop anyway)
-    bool done = false;
-    bool fin = nb == 0;
+    bool done = head_ended;
+    bool fin = nb == 0 || head_ended;
     int b = 0;                                   // phases this ray has marched (== the phase counter while it is live)
     bool epoch_staged = false;
     uint32_t off[BATCH] = {};                    // prepared LDS offsets of the next phase's samples
@@ -683,24 +714,8 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
     }
     if (hit && !done) {
-        const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
-        for (; i < P.max_steps; i++) {
-            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
-            float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
-            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
-            const int vi = min((int)(tcx * P.fdim[0]), nxm1);
-            const int vj = min((int)(tcy * P.fdim[1]), nym1);
-            const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-            float c, cg = 0.0f, cb = 0.0f, a;
-            classify((uint32_t)vol[VoxelAddr<1, true>::at(P, vi, vj, vk)], c, cg, cb, a);
-            accumulate(c, cg, cb, a);
-            qx += tsx; qy += tsy; qz += tsz;
-        }
+        for (; i < P.max_steps; i++)
+            if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
