@@ -147,9 +147,9 @@ int vr_set_accum(vr_handle h, int accum);            /* VR_ACCUM_*   (Q8)       
 int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*                   */
 int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_* (default BRICKED); re-lays the volume out */
 int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
-/* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches
-   of the headline shape with fewer than 256 active 32x16 tiles use the 4-wavefront relay kernel,
-   launches with fewer than 512 the fast kernel's software-pipelined loop),
+/* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches far from filling the
+   chip -- fewer than 256 active 32x16 tiles, 1024 when the view is oblique to the volume axes -- use the 4-wavefront
+   relay kernel; the fast kernel runs its software-pipelined batch loop unless alpha_scale >= 0.5),
    1 = always the generic line-by-line kernel (cross-check / debugging), 2 = the fast kernel with its
    plain loop: never the relay kernel, never the pipelined loop, 3 = automatic but always the relay kernel
    when the shape allows, 4 = the LDS-staged kernel (bricks streamed into LDS by LDS-DMA, vr_slab.hip)
