@@ -8,8 +8,8 @@
   still prints exactly ONE JSON line.
 
 A "step" is one frame: one launch of the ray-march kernel over this rank's image-row
-shard, plus (N>1) the RCCL all_gather + de-interleave that puts the whole frame on every
-rank.  Workload (config.workload): synthetic 1024^3 uint16 volume generated in HBM,
+shard, plus (N>1) the RCCL gather of the shards to rank 0 (--collective all_gather: to every rank) and the
+assembly kernel there (de-interleave + (grey, alpha) -> RGBA).  Workload (config.workload): synthetic 1024^3 uint16 volume generated in HBM,
 1920x1080 RGBA32F target, reference default camera, NEAREST sampling (the reference's
 effective filter), window [0,4095], alpha_scale 0.004 ("deep": no early ray
 termination, every ray traverses the whole box).  The frame is fixed while N grows
