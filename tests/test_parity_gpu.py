@@ -906,6 +906,25 @@ def test_relay_kernel_equals_fast_kernel(vra, oracle, variant):
                     assert_same(got, want, spp, want_spp, what=f"variant {variant} {dims} {dtype.__name__} layout {layout} {name}")
 
 
+def test_short_batches_for_high_opacity(vra, cfg3):
+    """alpha_scale >= 0.5 (rays end early): the host picks the fast kernel's 4-sample batches; the frame and the per-ray
+    sample counts equal the 8-sample loop's and the generic kernel's"""
+    r = cfg3
+    r.setAlpha(1.0)
+    frames, totals = [], []
+    for variant in (0, 2, 1):
+        r.setKernelVariant(variant)
+        r.render()
+        assert r.last_kernel_name == ("raymarch_generic_kernel" if variant == 1 else "raymarch_fast_kernel")
+        frames.append(r.readPixels())
+        totals.append(r.countSamples())
+    assert totals[0] == totals[1] == totals[2] == 139601127          # the shallow regime of BASELINE.md
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+    r.setKernelVariant(0)
+    r.setAlpha(0.004)
+
+
 def test_pipelined_loop_full_size_shard(vra, cfg3):
     """one rank's stripes of the cfg3 frame at N = 4 (335 tiles: under-filled, not sparse): the host picks the fast kernel's
     pipelined loop; the frame equals the plain loop's bit for bit"""

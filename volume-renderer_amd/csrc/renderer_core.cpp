@@ -617,6 +617,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.generic = force_generic == 1 ? 1 : 0;
     L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
     L.pipelined = 0;
+    L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
     {
         // VoxelAddr: the strides carry minus the part of the in-brick term the split axis repeats
@@ -857,6 +858,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
     L.pipelined = (force_generic == 0 && P.alpha_scale < 0.5f) ? 1 : 0;
+    L.short_batches = (force_generic == 0 && P.alpha_scale >= 0.5f) ? 1 : 0;     // 0.174 vs 0.190 ms at alpha = 1 (cfg3)
     if (force_generic == 5) { L.pipelined = 1; L.sparse_shard = 0; }   // kernel variant 5: fast kernel, pipelined loop, never the relay
 }
 

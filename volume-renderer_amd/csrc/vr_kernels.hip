@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
 {
     static_assert(BATCH == 8 || !SKIPT, "empty-space skipping assumes 8-sample batches");
     static_assert(!PIPE || (!SKIPT && !BIG), "the pipelined loop issues gathers for lanes without a next batch: bounds-checked buffer loads, no skip branch");
-    static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH == 8), "12-bit copy: u16 bricks through the address tables");
+    static_assert(!PK12 || (ATAB && sizeof(VoxelT) == 2 && LAYOUT == 1 && BATCH <= 8), "12-bit copy: u16 bricks through the address tables");
     __shared__ float lut[LUT ? (ATAB && BIG ? FAST_BIG_LUT_FLOATS : FAST_LUT_MAX * 2) : 4];   // 32 KiB: 4096 x (c,a) or 256 x (r,g,b,a) + index bytes
     __shared__ uint32_t axis_tab[ATAB ? (BIG ? FAST_AXIS_TAB_BIG_MAX : FAST_AXIS_TAB_MAX) : 1];
     static_assert(!(ATAB && BIG) || LAYOUT == 1, "64-bit address tables exist for the bricked layout");
@@ -1480,7 +1480,14 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
 {
     const FastGrid g = fast_grid(P.img_w, rows);
     const unsigned blocks = L.tile_table ? L.tile_table_blocks : g.blocks;
-    if constexpr (!SKIPT && !BIG && ATAB) {
+    if constexpr (!SKIPT && !BIG && ATAB && BATCH == 8) {
+        if (L.short_batches) {      // rays that end early (high opacity): 4-sample batches waste less behind the terminating sample
+            hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, 4, ATAB, PK12, false>), dim3(blocks),
+                               dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
+                               g.tiles_x, g.tiles_y, g.chunks_per_row, L.tile_table, L.skip_grid, L.skip_grid_bytes,
+                               PK12 ? L.packed12 : nullptr, PK12 ? L.packed12_bytes : 0u);
+            return hipGetLastError();
+        }
         if (L.pipelined) {          // under-filled launch: 16 gathers per lane in flight shorten the serial chain
             hipLaunchKernelGGL((raymarch_fast_kernel<VoxelT, LAYOUT, DIVTC, VIEW, BIG, LUT, POW2, NOCLAMP, MODE, SKIPT, BATCH, ATAB, PK12, true>), dim3(blocks),
                                dim3(FAST_THREADS), 0, st, P, (const VoxelT *)vol, tf, (uint32_t)L.vol_bytes32, fb, spp,
