@@ -240,14 +240,26 @@ vr_handle vr_group_member(vr_group_handle g, int rank);
    (balanced: only ~75 % of the rows hit the box at the default camera), 1 = contiguous row blocks */
 int vr_group_setup(vr_group_handle g, int win_w, int win_h, int fb_w, int fb_h, int partition, int stripe_rows);
 /* 1 (default): RCCL when every member has its own device; 0: always peer copies; 2: like 1, and a
-   one-member group also creates its communicator (a probe that RCCL loads and initialises here).
+   one-member group also creates its communicator and every shard -- the root's own included --
+   travels through a grouped ncclSend/ncclRecv (on a one-GPU box: a send to self, which executes
+   the same RCCL calls, datatype, counts and stream wiring as the multi-GPU gather).
    Call before vr_group_setup. */
 int vr_group_set_transport(vr_group_handle g, int use_rccl);
 const char *vr_group_transport(vr_group_handle g);     /* what vr_group_setup chose */
 /* render(): every member's shard kernel (concurrently, one stream per device), the gather and the
    assembly; blocks until the frame is complete on devices[0].  Adds the slowest member's kernel
-   time to the group's kerneltime_sum. */
+   time to the group's kerneltime_sum.  == vr_group_render_async + vr_group_wait. */
 int vr_group_render(vr_group_handle g);
+/* the same frame without the block (replaces the reference's blocking timer read-back,
+   src/RendererCore.cpp:152, for callers that can run a frame ahead): vr_group_render_async
+   enqueues the next frame into one of TWO frame slots -- shard kernels on the members' render
+   streams, gather and assembly on separate transfer streams -- and returns; at most two frames
+   may be in flight (VR_E_INVALID otherwise).  vr_group_wait blocks until the OLDEST frame in
+   flight is assembled and makes it the frame vr_group_framebuffer_device / vr_group_read_pixels
+   return.  Keeping one frame in flight overlaps the gather of frame i with the kernels of
+   frame i + 1. */
+int vr_group_render_async(vr_group_handle g);
+int vr_group_wait(vr_group_handle g);
 float vr_group_kernel_ms_take(vr_group_handle g);
 void *vr_group_framebuffer_device(vr_group_handle g);   /* fb_w x fb_h RGBA32F on devices[0] */
 int vr_group_read_pixels(vr_group_handle g, float *rgba, size_t n_floats);

@@ -222,8 +222,12 @@ def test_reference_datasets_when_supplied(vra, oracle, which, datasize, size):
     import os
 
     path = os.environ.get(which)
-    if not path or not os.path.exists(path):
-        pytest.skip(f"{which} not set")
+    name = "Bonsai 256x256x256 uint8 .raw (+ .raw.inf)" if which == "VR_DATA_BONSAI" else "Head CT 512x512x452 uint16 .pvm"
+    if not path:
+        pytest.skip(f"{which} is not set: the reference does not ship its datasets (upstream .gitignore:19-24) and this box has no network; "
+                    f"export {which}=/path/to/the {name} file to run this test (README.md, 'Real datasets')")
+    if not os.path.exists(path):
+        pytest.skip(f"{which}={path} does not exist on this box (expected the {name} file; README.md, 'Real datasets')")
     with vra.RendererCore(0) as r:
         r.setup(size)
         assert r.loadShader("VolumeRenderer.cs")

@@ -1052,3 +1052,110 @@ def test_trilinear_apron_copy_is_invisible(vra, oracle, dtype):
                     assert_same(with_copy, want, spp, want_spp, what=f"apron {dims} {name} mip={mip}")
             r.setLayout(R.LAYOUT_LINEAR); r.setTrilinearCopy(True); r.render()      # the linear layout has no apron copy
             assert r.trilinearCopyBytes() == 0
+
+
+def far_camera_blocks(oracle):
+    """eye 13..33 box sizes away (zoomed out, then orbited; the view-plane distance grows with the radius so that the
+    box still fills the image): o + d*t_min is then rounded to ~1e-6 of absolute error, more than the EPSILON*|d| nudge
+    of VolumeRenderer.cs:107 -- a few per cent of the HIT rays have their FIRST sample outside the box and end with
+    zero samples"""
+    out = []
+    for nz, ze, az in ((10, -0.9, 1.86), (20, 0.42, 0.54), (20, 0.3, -0.3), (30, 0.2, 0.9)):
+        c = oracle.Camera()
+        for _ in range(nz):
+            c.orient(-1.0, 0.0, 0.0)
+        c.orient(0, ze, az)
+        b = c.block().copy()
+        b[20] *= float(np.linalg.norm(b[16:19])) / 3.0
+        out.append((f"far{nz}", b))
+    return out
+
+
+def _first_sample_outside(block, W, H):
+    """float32 restatement of computeRay / intersectRayAABB / the first texcoord for a unit box (test bookkeeping only:
+    it says how many hit rays start outside, i.e. whether the test below exercises what it claims to)"""
+    f32 = np.float32
+    c = block.astype(f32)
+    px = (np.arange(W, dtype=f32) + f32(0.5))[None, :].repeat(H, 0)
+    py = (np.arange(H, dtype=f32) + f32(0.5))[:, None].repeat(W, 1)
+    fw, fh = f32(W), f32(H)
+    x = (fw / fh) * ((f32(2) * px) / fw - f32(1)); y = (f32(2) * py) / fh - f32(1); z = np.full_like(x, -c[20])
+    ln = np.sqrt((x * x + y * y) + z * z)
+    dx, dy, dz = x / ln, y / ln, z / ln
+    mx = (c[0] * dx + c[4] * dy) + c[8] * dz; my = (c[1] * dx + c[5] * dy) + c[9] * dz; mz = (c[2] * dx + c[6] * dy) + c[10] * dz
+    ln = np.sqrt((mx * mx + my * my) + mz * mz)
+    d, o = [mx / ln, my / ln, mz / ln], [c[16], c[17], c[18]]
+    tmin = np.full_like(x, -np.inf); tmax = np.full_like(x, np.inf)
+    with np.errstate(all="ignore"):
+        hit = np.ones_like(x, bool)
+        for a in range(3):
+            inv = f32(1) / d[a]
+            t0 = (f32(-0.5) - o[a]) * inv; t1 = (f32(0.5) - o[a]) * inv
+            tmin = np.maximum(tmin, np.minimum(t0, t1)); tmax = np.minimum(tmax, np.maximum(t0, t1))
+            if a == 1:
+                hit &= ~(tmax < tmin)
+        hit &= tmax > np.maximum(tmin, f32(0))
+        outside = np.zeros_like(hit)
+        for a in range(3):
+            u = ((o[a] + d[a] * tmin) + d[a] * f32(1e-6)) + f32(0.5)
+            outside |= (u > 1) | (u < 0)
+    return int((hit & outside).sum())
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5], ids=["auto", "fast", "relay", "slab", "pipelined"])
+def test_rays_that_end_inside_their_checked_head(vra, oracle, variant):
+    """round-2 advisor finding: the relay kernel composited its prefix batches and tail onto rays whose first sample
+    fails the bounds test (the shader, and every other kernel, end such a ray with zero samples).  Far cameras make
+    those rays common; every kernel variant must give the oracle's frame and per-pixel fetch counts."""
+    rng = np.random.default_rng(404)
+    R = vra.renderer
+    W, H = 120, 88
+    blocks = far_camera_blocks(oracle)
+    assert sum(_first_sample_outside(b, W, H) for _, b in blocks) > 500
+    for dtype, dims, win in ((np.uint8, (64, 64, 64), (0, 255)), (np.uint16, (64, 64, 64), (0, 4095))):
+        vol = rand_volume(rng, dims, dtype, smooth=True)
+        vol[:] = np.maximum(vol, 40 if dtype == np.uint8 else 600)      # every sample visible: a ray with samples shows
+        for filt in (R.FILTER_NEAREST, R.FILTER_TRILINEAR):
+            with make_renderer(vra, (W, H)) as r:
+                r.setQuirks(0); r.setKernelVariant(variant); r.setVolume(vol); r.setWindow(*win); r.setAlpha(0.05); r.setFilter(filt)
+                for name, block in blocks:
+                    r.setCameraBlock(block)
+                    r.render()
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    kernel = r.last_kernel_name
+                    p = oracle.OracleParams(W, H, cam=block, alpha_scale=0.05, min_val=win[0], max_val=win[1],
+                                            filter=int(filt == R.FILTER_TRILINEAR))
+                    want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                    assert_same(got, want, spp, want_spp, what=f"variant {variant} {np.dtype(dtype).name} filter {filt} {name} kernel {kernel}")
+                    if variant == 3 and filt == R.FILTER_NEAREST:
+                        assert kernel == "raymarch_relay_kernel"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2], ids=["auto", "generic", "fast"])
+def test_step_budget_of_10000_samples(vra, oracle, variant):
+    """Q6: the shader's loop runs at most 10000 iterations (VolumeRenderer.cs:115).  A 16384 x 2 x 2 volume in a unit
+    box has a step of ~1e-4, so every ray that crosses the box takes the cap; the checked head + the prefix batches
+    must not take one sample more (round-2 advisor finding: head + nb * BATCH could exceed max_steps)."""
+    rng = np.random.default_rng(10000)
+    R = vra.renderer
+    dims = (16384, 2, 2)
+    vol = rng.integers(0, 256, size=(dims[2], dims[1], dims[0]), dtype=np.uint8)
+    spacing = (1.0, 4096.0, 4096.0)                         # box 1 x 0.5 x 0.5, step 7.5e-5: 13 000 steps along x
+    W, H = 96, 64
+    for alpha in (0.00005, 1.0):
+        capped = 0
+        with make_renderer(vra, (W, H)) as r:
+            r.setQuirks(0); r.setKernelVariant(variant); r.setVolume(vol, spacing); r.setWindow(0, 255); r.setAlpha(alpha)
+            for ze, az in ((0.0, 2.244), (0.3, 2.1), (-0.9, 0.7)):
+                r.resetCamera(); r.cameraOrient(0.0, ze, az)
+                block = r.getCameraBlock()
+                r.render()
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=0, max_val=255)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                capped += int((want_spp == 10000).sum())
+                assert int(want_spp.max()) <= 10000
+                assert_same(got, want, spp, want_spp, what=f"10000-step cap variant {variant} alpha {alpha} pose ({ze}, {az}) kernel {r.last_kernel_name}")
+        assert alpha == 1.0 or capped >= 200, capped

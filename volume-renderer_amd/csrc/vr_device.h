@@ -294,8 +294,9 @@ struct VoxelFetch {
 
 // Number of leading samples of a ray whose texcoords are provably inside (0,1)^3 (see the
 // fast kernel's header): q = first sample position, ds = per-sample step, box units.
+// budget = samples the shader's loop has left for this ray (max_steps minus the checked head's samples)
 __device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx, float qy, float qz, float dsx,
-                                                  float dsy, float dsz)
+                                                  float dsy, float dsz, int budget)
 {
     // B bounds |pos| for every sample that is still inside the box
     const float hm = fmaxf(fmaxf(P.half[0], P.half[1]), P.half[2]);
@@ -318,8 +319,8 @@ __device__ __forceinline__ int safe_prefix_length(const FrameParams &P, float qx
     int k_safe = 0;
     if (ok && kmax > 4.0f) k_safe = (int)(kmax * 0.999f) - 2;
     if (!(k_safe > 0)) k_safe = 0;
-    if (k_safe > P.max_steps) k_safe = P.max_steps;
-    return k_safe;
+    if (k_safe > budget) k_safe = budget;
+    return k_safe > 0 ? k_safe : 0;
 }
 
 // The first sample of a ray sits EPSILON * |dir| = 1e-6 * |dir_a| inside the face it entered through -- closer to it

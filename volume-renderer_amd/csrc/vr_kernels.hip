@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
         for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
         // ---- safe prefix length (samples head .. head + k_safe - 1)
-        const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+        const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz, P.max_steps - head) : 0;
 
         // texcoord -> voxel index of a position; valid (unclamped) inside the prefix
         auto voxel_of = [&](float ax, float ay, float az, int &vi, int &vj, int &vk) {
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     const float hqx = qx, hqy = qy, hqz = qz;
     const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
-    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz, P.max_steps - head) : 0;
     const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
 
     // texcoord * dim of a position (before the -0.5 of the linear filter)
@@ -1038,7 +1038,26 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     const float hqx = qx, hqy = qy, hqz = qz;
     const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
-    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    // A ray can END inside its head: a head sample fails the shader's bounds test (o + d*t_min rounds to a point
+    // outside the box when the eye is far away) or the step budget runs out.  That part of the head does not depend
+    // on the voxel data, so every wavefront of the relay evaluates it for itself: such a ray has no prefix batches
+    // and no tail (wavefront 0's literal head loop below stops at the same sample).
+    bool head_ended = false;
+    {
+        float x = hqx, y = hqy, z = hqz;
+        for (int h = 0; h < head && !head_ended; h++) {
+            const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            if (h >= P.max_steps || tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f) head_ended = true;
+            x += dsx; y += dsy; z += dsz;
+        }
+    }
+    const int k_safe = (hit && !head_ended) ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz, P.max_steps - head) : 0;
     const int nb = k_safe / RELAY_BATCH;                 // batches of THIS ray
     int nbmax = nb;                                      // batches of the tile (same in all 4 wavefronts)
     for (int o = 32; o > 0; o >>= 1) nbmax = max(nbmax, __shfl_xor(nbmax, o));
@@ -1262,7 +1281,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     }
     if (POW2) { qx = qx / Sx; qy = qy / Sy; qz = qz / Sz; }   // exact: S is a power of two
     const float tsx = POW2 ? mx / Sx : mx, tsy = POW2 ? my / Sy : my, tsz = POW2 ? mz / Sz : mz;
-    if (hit) {
+    if (hit && !head_ended) {
         const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
         for (; i < P.max_steps; i++) {
             const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     const float hqx = qx, hqy = qy, hqz = qz;
     const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
     for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
-    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz, P.max_steps - head) : 0;
     const int nb = k_safe / BATCH;                                      // phases of this ray's prefix
 
     // marching units: voxels for POW2 (exact, see raymarch_fast_kernel), box units otherwise

@@ -152,6 +152,8 @@ def load_library() -> C.CDLL:
         "vr_group_set_transport": (i32, [h, i32]),
         "vr_group_transport": (C.c_char_p, [h]),
         "vr_group_render": (i32, [h]),
+        "vr_group_render_async": (i32, [h]),
+        "vr_group_wait": (i32, [h]),
         "vr_group_kernel_ms_take": (f32, [h]),
         "vr_group_framebuffer_device": (C.c_void_p, [h]),
         "vr_group_read_pixels": (i32, [h, C.POINTER(f32), C.c_size_t]),
@@ -255,6 +257,13 @@ class RendererGroup:
 
     def render(self):
         self._check(self._lib.vr_group_render(self._g))
+
+    def renderAsync(self):
+        """enqueue the next frame (at most two in flight); wait() completes the oldest"""
+        self._check(self._lib.vr_group_render_async(self._g))
+
+    def wait(self):
+        self._check(self._lib.vr_group_wait(self._g))
 
     def kernelMsTake(self) -> float:
         return float(self._lib.vr_group_kernel_ms_take(self._g))

@@ -120,6 +120,7 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
     if plan.world == 1:
         frame = local[: plan.img_h]
         return expand_grey_alpha(frame) if grey_alpha else frame
+    caller_owns_out = out is not None
     if out is None:
         out = torch.empty((plan.world * plan.local_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if root is not None:
@@ -127,11 +128,14 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
         staged = local.is_cuda and dist.get_backend() == "gloo"      # validation hook: ranks sharing one GPU gather through host memory
         if is_root:
             dst = torch.empty(out.shape, dtype=out.dtype) if staged else out
-            key = (dst.data_ptr(), tuple(dst.shape), plan.world)
-            pieces = _GATHER_VIEWS.get(key) if not staged else None
-            if pieces is None:              # the per-rank views of a gather buffer are built once, not per frame
+            # the per-rank views of a CALLER-OWNED gather buffer are built once, not per frame (a buffer allocated
+            # above lives for this call only: caching its views would pin it)
+            cacheable = caller_owns_out and not staged
+            key = (dst.data_ptr(), tuple(dst.shape), plan.world, str(dst.dtype), str(dst.device))
+            pieces = _GATHER_VIEWS.get(key) if cacheable else None
+            if pieces is None:
                 pieces = list(dst.view((plan.world, plan.local_rows) + tuple(local.shape[1:])).unbind(0))
-                if not staged:
+                if cacheable:
                     if len(_GATHER_VIEWS) > 16:
                         _GATHER_VIEWS.clear()
                     _GATHER_VIEWS[key] = pieces
