@@ -154,7 +154,9 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    plain loop: never the relay kernel, never the pipelined loop, 3 = automatic but always the relay kernel
    when the shape allows, 4 = the LDS-staged kernel (bricks streamed into LDS by LDS-DMA, vr_slab.hip)
    wherever it is eligible -- bit-identical frames; measured slower than the default kernels on MI355X
-   (DESIGN.md section 6), kept as an opt-in, 5 = the fast kernel with the pipelined loop, never the relay.
+   (DESIGN.md section 6), kept as an opt-in, 5 = the fast kernel with the pipelined loop, never the relay,
+   6 = TRILINEAR on the LDS-staged kernel (the apron copy's bricks streamed into LDS, eight ds_read taps per
+   sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible.
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the

@@ -72,19 +72,25 @@ def test_rccl_self_send_recv_moves_the_shard(vra, tf):
     rng = np.random.default_rng(11)
     vol = rng.integers(0, 256, size=(48, 40, 56), dtype=np.uint8)
     size = (203, 157)
+    poses = [(0.06 * 5, 0.06 * 11), (0.06 * 2, -0.06 * 7), (-0.06 * 9, 0.06 * 3), (0.06, 0.06)]
+    want = []
     with vra.RendererCore(0) as single:
         single.setup(size)
         configure(single, vra, vol, tf)
-        single.render()
-        want = single.readPixels()
+        for ze, az in poses:
+            single.resetCamera(); single.cameraOrient(0, ze, az)
+            single.render()
+            want.append(single.readPixels())
+    assert not np.array_equal(bits(want[0]), bits(want[2]))
     with vra.RendererGroup([0]) as g:
         g.setTransport(2)
         g.setup(size)
         assert "self send/recv" in g.transport, g.transport
         g.each(lambda m: configure(m, vra, vol, tf))
-        for _ in range(3):                              # both frame slots, and a slot re-used
+        for k, (ze, az) in enumerate(poses):            # both frame slots, each re-used; a different frame every time: stale bytes show
+            g.each(lambda m: (m.resetCamera(), m.cameraOrient(0, ze, az)))
             g.render()
-            assert np.array_equal(bits(g.readPixels()), bits(want))
+            assert np.array_equal(bits(g.readPixels()), bits(want[k])), k
 
 
 @pytest.mark.parametrize("n", [1, 2, 4])

@@ -616,6 +616,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
     L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
+    L.tri_slab = force_generic == 6 ? 1 : 0;                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -726,9 +727,9 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     L.apron = nullptr;
     L.apron_bytes = 0;
     last_apron_bytes_ = 0;
-    if (!tri_apron || apron_failed_ || vol_layout_ != 1 || !tri_path_candidate(P, L)) return;
+    if (!tri_apron || apron_failed_ || vol_layout_ != 1 || !(tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const uint64_t bytes = apron_voxels(res_dims_[0], res_dims_[1], res_dims_[2]) * (uint64_t)res_bytes_;
-    if (bytes + 16 >= (1ull << 32)) return;
+    if (bytes + 16 >= (1ull << 32) && !tri_slab_candidate(P, L)) return;   // the batched kernel gathers through a 32-bit buffer descriptor
     if (!d_apron_) {
         if (hipMalloc(&d_apron_, bytes + 16) != hipSuccess) {         // an optimisation only
             (void)hipGetLastError();
@@ -746,7 +747,7 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
         apron_bytes_ = (size_t)bytes;
     }
     L.apron = d_apron_;
-    L.apron_bytes = (uint32_t)apron_bytes_;
+    L.apron_bytes = (uint64_t)apron_bytes_;
     last_apron_bytes_ = apron_bytes_;
 }
 
@@ -818,7 +819,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
 {
     L.tile_table = nullptr;
     L.tile_table_blocks = 0;
-    if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L))) return;
+    if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
     // The table must list exactly the tiles of this image / shard (shape key); the camera only

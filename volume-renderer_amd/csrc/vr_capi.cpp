@@ -323,7 +323,7 @@ int vr_set_skip_empty(vr_handle h, int enable)
 int vr_set_kernel_variant(vr_handle h, int variant)
 {
     return guarded(h, [&](vr::RendererCore &c) {
-        if (variant < 0 || variant > 5) throw std::invalid_argument("unknown kernel variant");
+        if (variant < 0 || variant > 6) throw std::invalid_argument("unknown kernel variant");
         c.force_generic = variant;
     });
 }

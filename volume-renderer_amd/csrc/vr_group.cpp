@@ -348,32 +348,34 @@ int vr_group_render_async(vr_group_handle g)
     hipStream_t gs = g->gather_stream;
     char *dst = static_cast<char *>(g->gathered[s]);
     if (rccl) {
-        // every member's send goes on its transfer stream behind its kernel; the root's receives (and, in probe mode,
-        // its send to itself) on the gather stream
+        // every member's send goes on its transfer stream behind its kernel; the root's receives on the gather stream.
+        // Every communicator sees ONE stream: in probe mode the root's send to itself is issued on the gather stream
+        // like its receives (RCCL 2.26 does not order a self send/recv that straddles two streams of one communicator
+        // with the later work of the receiving stream -- measured here: the assembly ran before the bytes arrived).
         const bool self = n == 1 || g->want_rccl == 2;                  // the root's own shard through ncclSend/ncclRecv too
-        for (int r = 0; r < n; r++) {
+        for (int r = 1; r < n; r++) {
             VRG_HIP(hipSetDevice(g->devices[(size_t)r]));
             VRG_HIP(hipStreamWaitEvent(g->xfer[(size_t)r], g->rendered[s][(size_t)r], 0));
         }
+        VRG_HIP(hipSetDevice(g->devices[0]));
+        VRG_HIP(hipStreamWaitEvent(gs, g->rendered[s][0], 0));
         rccl_result_t rc = g_rccl.GroupStart();
         for (int r = self ? 0 : 1; r < n && rc == kRcclSuccess; r++) {
             rc = g_rccl.Recv(dst + (size_t)r * shard_bytes, shard_floats, kRcclFloat32, r, g->comms[0], gs);
             if (rc == kRcclSuccess)
-                rc = g_rccl.Send(g->local[s][(size_t)r], shard_floats, kRcclFloat32, 0, g->comms[(size_t)r], g->xfer[(size_t)r]);
+                rc = g_rccl.Send(g->local[s][(size_t)r], shard_floats, kRcclFloat32, 0, g->comms[(size_t)r], r == 0 ? gs : g->xfer[(size_t)r]);
         }
         const rccl_result_t rc2 = g_rccl.GroupEnd();
         if (rc != kRcclSuccess || rc2 != kRcclSuccess)
             return gfail(g, VR_E_HIP, std::string("rccl gather: ") + g_rccl.GetErrorString(rc != kRcclSuccess ? rc : rc2));
-        for (int r = self ? 0 : 1; r < n; r++) {
+        for (int r = 1; r < n; r++) {
             VRG_HIP(hipSetDevice(g->devices[(size_t)r]));
             VRG_HIP(hipEventRecord(g->sent[s][(size_t)r], g->xfer[(size_t)r]));
         }
         VRG_HIP(hipSetDevice(g->devices[0]));
-        if (!self) {                                                    // the root's own shard: a plain copy on its device
-            VRG_HIP(hipStreamWaitEvent(gs, g->rendered[s][0], 0));
+        if (!self)                                                      // the root's own shard: a plain copy on its device
             VRG_HIP(hipMemcpyAsync(dst, g->local[s][0], shard_bytes, hipMemcpyDeviceToDevice, gs));
-            VRG_HIP(hipEventRecord(g->sent[s][0], gs));
-        }
+        VRG_HIP(hipEventRecord(g->sent[s][0], gs));
     } else {
         VRG_HIP(hipSetDevice(g->devices[0]));
         for (int r = 0; r < n; r++) {

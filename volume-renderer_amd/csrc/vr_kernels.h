@@ -16,6 +16,11 @@ bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L);
 // layout with u8 voxels or the 12-bit packed copy, a classification table, torus tables that fit
 bool slab_path_eligible(const FrameParams &P, const LaunchConfig &L);
 
+// TRILINEAR on the LDS-staged kernel (vr_slab.hip, TRI): the trilinear path's preconditions with any mode (grey, MIP,
+// transfer function), the bricked layout with its apron copy resident, torus tables that fit LDS; volumes beyond
+// 32-bit offsets included
+bool tri_slab_candidate(const FrameParams &P, const LaunchConfig &L);
+
 // local image rows one launch covers (stripe padding included)
 int launch_local_rows(const FrameParams &P);
 

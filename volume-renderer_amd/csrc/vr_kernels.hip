@@ -1667,7 +1667,7 @@ static hipError_t dispatch_tri(const FrameParams &P, const LaunchConfig &L, cons
     do {                                                                                                         \
         if (LAYOUT == 1 && L.apron != nullptr) {                                                                 \
             hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP, LAYOUT == 1>), grid, block, 0, st, P, \
-                               (const VoxelT *)L.apron, L.apron_bytes, fb, spp, L.tile_table);                    \
+                               (const VoxelT *)L.apron, (uint32_t)L.apron_bytes, fb, spp, L.tile_table);                    \
             return hipGetLastError();                                                                            \
         }                                                                                                        \
         hipLaunchKernelGGL((raymarch_tri_kernel<VoxelT, LAYOUT, TC, VW, P2, MP, false>), grid, block, 0, st, P,   \
@@ -1772,6 +1772,28 @@ hipError_t launch_raymarch_slab_pk12(const FrameParams &P, const LaunchConfig &L
 
 static bool tri_path_eligible(const FrameParams &P, const LaunchConfig &L) { return tri_path_candidate(P, L) && L.tile_table != nullptr; }
 
+// TRILINEAR on the LDS-staged kernel (vr_slab.hip): every mode (the 256-entry transfer-function table sits in LDS), any
+// volume size (64-bit DMA addresses), the bricked layout; the apron copy must be resident (host: refreshApron)
+bool tri_slab_candidate(const FrameParams &P, const LaunchConfig &L)
+{
+    if (L.generic || L.filter != 1 || P.accum != 0 || !(P.fden > 0.0f) || !(P.max_val > P.min_val) || L.divmode_win != DIV_CERT ||
+        L.divmode_tc == DIV_EXACT || !(P.alpha_scale >= 0.0f && P.alpha_scale <= 1.0f) || L.layout != 1) return false;
+    if (P.tf_len > 256) return false;
+    const uint64_t bricks = (uint64_t)P.bnx * (uint64_t)P.bny * (uint64_t)P.bnz;
+    if (bricks >= (1ull << 32) || (uint64_t)P.bnx * (uint64_t)P.bny >= (1ull << 24)) return false;
+    return P.nx + P.ny + P.nz <= (L.bytes_per_voxel == 1 ? 6144 : 3072);
+}
+
+static bool tri_slab_selected(const FrameParams &P, const LaunchConfig &L)
+{
+    return L.tri_slab && L.apron != nullptr && L.tile_table != nullptr && tri_slab_candidate(P, L);
+}
+
+hipError_t launch_raymarch_slab_tri_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                       uint32_t *spp, hipStream_t st);
+hipError_t launch_raymarch_slab_tri_u16(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                        uint32_t *spp, hipStream_t st);
+
 int launch_local_rows(const FrameParams &P)
 {
     int rows;
@@ -1797,6 +1819,10 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
 {
     const int rows = launch_local_rows(P);   // local image rows covered by this launch
     if (rows <= 0 || P.img_w <= 0) return hipSuccess;
+    if (tri_slab_selected(P, L)) {
+        if (kernel_name) *kernel_name = "raymarch_slab_tri_kernel";
+        return L.bytes_per_voxel == 1 ? launch_raymarch_slab_tri_u8(P, L, vol, tf, fb, spp, st) : launch_raymarch_slab_tri_u16(P, L, vol, tf, fb, spp, st);
+    }
     const int fast = fast_path_eligible(P, L) ? 1 : (tri_path_eligible(P, L) ? 2 : 0);
     const bool slab = fast == 1 && slab_selected(P, L);
     if (kernel_name)
