@@ -1,7 +1,8 @@
-// the cfg3 instance of the LDS-staged TRILINEAR kernel (u16, POW2, composite) alone, for ISA inspection
-#define VR_SLAB_TU 99
-#include "../../volume-renderer_amd/csrc/vr_slab.hip"
+// the cfg3 instance of the LDS-staged TRILINEAR kernel (u16, POW2, composite) alone, for ISA inspection:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --cuda-device-only -S -o /tmp/tslab.s tools/isa/probe_tslab.hip
+#define VR_TSLAB_TU 99
+#include "../../volume-renderer_amd/csrc/vr_tslab.hip"
 namespace vr {
-template __global__ void raymarch_slab_kernel<uint16_t, false, 0, 0, true, false, 0, true>(const FrameParams, const uint16_t *, const uint8_t *, const float4 *,
-                                                                                            float4 *, uint32_t *, const uint32_t *);
+template __global__ void raymarch_tslab_kernel<uint16_t, 0, 0, true, 0>(const FrameParams, const uint16_t *, const uint8_t *, const float4 *, float4 *, uint32_t *,
+                                                                         const uint32_t *);
 }

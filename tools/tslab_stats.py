@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""experiment (needs a stats build of vr_tslab.hip: make TSLAB_TAG=_st TSLAB_DEFS="-DVR_EXPERIMENTS -DVR_X_STATS", then
+VR_CORE_LIB=.../libvr_core_st.so): per-tile load-plan statistics of the LDS-staged TRILINEAR kernel on the bench workload.
+  tools/tslab_stats.py [default|offaxis] [N] [bytes]"""
+import importlib, sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+vra = importlib.import_module("volume-renderer_amd")
+R = vra.renderer
+pose = sys.argv[1] if len(sys.argv) > 1 else "default"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+b = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+W, H = (1920, 1080) if N <= 1024 else (3840, 2160)
+r = vra.RendererCore(0)
+r.setup((W, H)); r.loadShader("x"); r.setQuirks(0)
+r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
+r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
+if pose == "offaxis":
+    r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+r.setKernelVariant(6)
+r.render()
+print("kernel", r.last_kernel_name)
+_, spp = r.countSamples(per_pixel=True)
+st = spp[::16, ::32]
+m = (st & 0x80000000) != 0
+v = st[m]
+staged, rz, slots, phases = v & 1, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 4095
+print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}); RZ histogram {np.bincount(rz)[:6]}; "
+      f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
+      f"RA*RB of unstaged tiles {np.unique(slots[staged == 0])[:20]}; phases mean {phases.mean():.1f} max {phases.max()}")
+for _ in range(150):
+    r.renderAsync()
+r.synchronize(); r.render(); r.kernelMsTake()
+for _ in range(20):
+    r.render()
+print("kernel ms", r.kernelMsTake() / 20)

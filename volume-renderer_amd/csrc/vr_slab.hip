@@ -34,85 +34,11 @@
 // Correctness does not depend on the plan being tight, only on it being a superset; every
 // parity test compares whole frames bit for bit, so a brick missing from LDS cannot hide.
 //
-//
-// TRI (round 3): the same machinery for TRILINEAR sampling (VolumeRenderer.cs:121 with the linear filter state of
-// src/RendererCore.cpp:414-415; GL's rule with the fixed lerp order x, y, z of oracle/vr_oracle.c).  The batched
-// trilinear kernel of vr_kernels.hip is bound by the vector L1's line-processing rate (27 M gather instructions x
-// ~8 lines x 4 cycles) AND by ~130 VALU per sample; here the eight taps of a sample are ds_read_u16 / ds_read_u8:
-//   * staged source = the APRON copy of the volume (vr_device.h: every 4x4x4 brick stored as 5x4x4, its last x
-//     column's neighbours included): a slot is 160 B (u16) / 80 B (u8), the x1 tap of every corner pair is the x0
-//     tap's address + one element (a ds_read immediate offset), so a sample needs FOUR tap addresses -- X[i0] + Y[j0|j1] +
-//     Z[k0|k1] -- from five torus-table look-ups; 160-byte slots also spread the bricks of one sheet over the LDS
-//     banks (128-byte slots: 2-3x the bank conflicts, tools/ubench/lds_taps.hip);
-//   * no clamps in the prefix: u = max(texcoord*N - 0.5, 0) makes the low edge exact (cell 0 with weight 0 == the
-//     shader's two clamped taps of voxel 0), the high edge is the apron column (x) or a duplicated last table entry
-//     (y, z): tables hold N + 1 entries per axis;
-//   * the load plan's bounds grow by half a voxel on either side (taps at floor(f - 0.5) and + 1).
-// Head, tail and epochs that do not fit the torus sample the resident volume with plain global loads.
-//
 // No MFMA: the path is a gather + a 25-flop recurrence per sample.
 #include "vr_device.h"
+#include "vr_lds_dma.h"
 
 namespace vr {
-
-#define VR_LDS_AS __attribute__((address_space(3)))
-
-__device__ __forceinline__ uint32_t lds_offset_of(const void *p) { return (uint32_t)(size_t)(VR_LDS_AS const char *)p; }
-
-// one 1-KiB piece of LDS-DMA: lane l's 16 bytes from gsrc land at lds_dst + 16*l (lds_dst is
-// wave-uniform and goes through M0; lanes switched off by EXEC leave their 16 bytes alone).
-// The compiler does not count this load: completion is waited for with slab_wait_pieces().
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
-{
-    unsigned keep;
-    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-// wait until at most n of this wavefront's vector-memory operations are outstanding (they
-// complete in order, so everything issued before the last n has landed)
-__device__ __forceinline__ void slab_wait_pieces(int n)
-{
-    switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    }
-}
-
-__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-__device__ __forceinline__ int uniform_i(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
-// wavefront-wide min / max of a float (result uniform): four DPP steps inside each row of 16 lanes, then
-// the four rows through readlane -- 11 instructions, no LDS crossbar
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
-{
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float readlane_f(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
-__device__ __forceinline__ float wave_min_f(float v)
-{
-    v = fminf(v, dpp_f<0xB1>(v));      // quad_perm [1,0,3,2]
-    v = fminf(v, dpp_f<0x4E>(v));      // quad_perm [2,3,0,1]
-    v = fminf(v, dpp_f<0x141>(v));     // row_half_mirror
-    v = fminf(v, dpp_f<0x140>(v));     // row_mirror
-    return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
-}
-template <typename T> __device__ __forceinline__ T sel3(int ax, T v0, T v1, T v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
 constexpr int SLAB_NW = 8, SLAB_THREADS = 64 * SLAB_NW;   // one 32x16-pixel tile per workgroup, like the fast kernel
 #if defined(VR_EXPERIMENTS) && defined(VR_X_PHASE)
@@ -136,43 +62,32 @@ constexpr int SLAB_LDS_BYTES = VR_X_LDSKB * 1024 - 512;
 constexpr int SLAB_LDS_BYTES = 80 * 1024 - 512;           // two workgroups per CU (160 KiB)
 #endif
 constexpr float SLAB_MARGIN = 0.0625f; // voxels: covers the rounding of the iterated positions over an epoch (< 2^-7 voxel for N <= 4096)
+constexpr int SLAB_MAX_PIECES = 2;     // 1-KiB pieces per wavefront per layer
 
-// LDS budget of one (voxel type, packing, mode, filter) family
-template <typename VoxelT, bool PK12, int MODE, bool TRI>
+// LDS budget of one (voxel type, packing, mode) family
+template <typename VoxelT, bool PK12, int MODE>
 struct SlabCfg {
-    // bytes per brick slot: NEAREST stages the bricked volume (64 B of u8) or its 12-bit packed copy (96 B);
-    // TRILINEAR stages the apron copy (5x4x4 voxels: 80 B of u8, 160 B of u16)
-    static constexpr int SLOT = TRI ? (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT) : (PK12 ? 96 : 64 * (int)sizeof(VoxelT));
+    static constexpr int SLOT = PK12 ? 96 : 64 * (int)sizeof(VoxelT);   // bytes per brick slot
     static constexpr int CH = SLOT / 16;                                 // 16-byte chunks per slot
     static constexpr int LUT_ENTRIES = sizeof(VoxelT) == 1 ? 256 : 4096;
-    // NEAREST grey modes: u8 -> 256 (c, a) pairs; 12-bit -> NO table: the window map is computed per sample with the
+    // grey modes: u8 -> 256 (c, a) pairs; 12-bit -> NO table: the window map is computed per sample with the
     // shader's own operations (certified quotient: 6 VALU instead of one more LDS round trip) and the
     // 32 KiB it would take go to the ring, which is what decides how far ahead the loads can run;
-    // transfer function: 256 RGBA entries + one index byte per window value.
-    // TRILINEAR: the interpolated sample is not an integer, so only the 256 RGBA entries can be tabulated
-    static constexpr bool HAS_LUT = TRI ? MODE >= 2 : (MODE >= 2 || sizeof(VoxelT) == 1);
-    static constexpr int LUT_BYTES = TRI ? (MODE >= 2 ? 4096 : 16) : (MODE >= 2 ? 4096 + LUT_ENTRIES : (sizeof(VoxelT) == 1 ? LUT_ENTRIES * 8 : 16));
-    // nx + ny + nz (+ one duplicated last entry per axis for TRILINEAR's + 1 taps)
-    static constexpr int TAB_AXES = sizeof(VoxelT) == 1 ? 6144 : 3072;
-    static constexpr int TAB_ENTRIES = TAB_AXES + (TRI ? 4 : 0);
+    // transfer function: 256 RGBA entries + one index byte per window value
+    static constexpr bool HAS_LUT = MODE >= 2 || sizeof(VoxelT) == 1;
+    static constexpr int LUT_BYTES = MODE >= 2 ? 4096 + LUT_ENTRIES : (sizeof(VoxelT) == 1 ? LUT_ENTRIES * 8 : 16);
+    static constexpr int TAB_ENTRIES = sizeof(VoxelT) == 1 ? 6144 : 3072;   // nx + ny + nz
     static constexpr int MISC_BYTES = 1024;
-    static constexpr int MAX_PIECES = TRI ? 3 : 2;                       // 1-KiB pieces per wavefront per layer
     // torus tables: 16-bit entries while the ring stays below 64 KiB (two workgroups per CU), 32-bit beyond
     static constexpr bool WIDE_TAB = SLAB_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES > 65535 + 16384;
     static constexpr int TAB_BYTES = TAB_ENTRIES * (WIDE_TAB ? 4 : 2);
     static constexpr int RING_RAW = SLAB_LDS_BYTES - LUT_BYTES - TAB_BYTES - MISC_BYTES;
     static constexpr int RING_BYTES = (!WIDE_TAB && RING_RAW > 65535 ? 65535 : RING_RAW) / SLOT * SLOT;
     static constexpr int CAP = RING_BYTES / SLOT;                           // brick slots
-    static constexpr int LAYER_SLOTS_MAX = MAX_PIECES * SLAB_NW * 64 / CH;
+    static constexpr int LAYER_SLOTS_MAX = SLAB_MAX_PIECES * SLAB_NW * 64 / CH;
 };
 
-#if defined(VR_EXPERIMENTS) && defined(VR_X_TRI_PHASE)
-constexpr int SLAB_TRI_PHASE = VR_X_TRI_PHASE;
-#else
-constexpr int SLAB_TRI_PHASE = 4;      // TRILINEAR: samples per phase (each carries 4 tap addresses + 3 weights in registers)
-#endif
-
-template <typename VoxelT, bool PK12, int DIVTC, int VIEW, bool POW2, bool NOCLAMP, int MODE, bool TRI = false>
+template <typename VoxelT, bool PK12, int DIVTC, int VIEW, bool POW2, bool NOCLAMP, int MODE>
 __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const FrameParams P,
                                                                         const VoxelT *__restrict__ vol,
                                                                         const uint8_t *__restrict__ src,
@@ -181,14 +96,10 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                                                                         uint32_t *__restrict__ spp,
                                                                         const uint32_t *__restrict__ tile_table)
 {
-    using C = SlabCfg<VoxelT, PK12, MODE, TRI>;
+    using C = SlabCfg<VoxelT, PK12, MODE>;
     static_assert(!PK12 || sizeof(VoxelT) == 2, "the 12-bit packed copy belongs to u16 volumes");
-    static_assert(TRI || PK12 || sizeof(VoxelT) == 1, "raw staging is built for u8 volumes (64-byte bricks)");
-    static_assert(!TRI || (!PK12 && !NOCLAMP), "TRILINEAR stages the apron copy of the volume itself");
-    constexpr int BATCH = TRI ? SLAB_TRI_PHASE : SLAB_PHASE;
-    // half a voxel more on either side of the load plan's bounds: the taps of a sample at scaled texcoord f are the
-    // voxels floor(f - 0.5) and floor(f - 0.5) + 1 per axis
-    constexpr float MGN = SLAB_MARGIN + (TRI ? 0.5f : 0.0f);
+    static_assert(PK12 || sizeof(VoxelT) == 1, "raw staging is built for u8 volumes (64-byte bricks)");
+    constexpr int BATCH = SLAB_PHASE;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::RING_BYTES];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
     using TabT = typename std::conditional<C::WIDE_TAB, uint32_t, uint16_t>::type;
@@ -230,7 +141,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     }
     // ---- classification table, with the shader's own operations (see raymarch_fast_kernel)
     if (C::HAS_LUT) {
-        const int n = TRI ? 0 : P.max_val - P.min_val + 1;      // TRILINEAR: no per-value table, the interpolated sample is classified arithmetically
+        const int n = P.max_val - P.min_val + 1;
         for (int e = (int)threadIdx.x; e < n; e += SLAB_THREADS) {
             const float s = (float)(P.min_val + e);
             const float v = div_cert(s - P.fmin, P.fden, P.rden);
@@ -324,10 +235,10 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     int pieces = 1;                                                     // 1-KiB pieces per wavefront per layer
     // per-lane loader constants of piece q: torus coordinates (ta, tb) of the slot this lane's 16-byte chunk
     // belongs to, the chunk's index inside the slot, and whether the slot exists
-    int ld_ta[C::MAX_PIECES], ld_tb[C::MAX_PIECES], ld_part[C::MAX_PIECES];
-    bool ld_ok[C::MAX_PIECES];
+    int ld_ta[SLAB_MAX_PIECES], ld_tb[SLAB_MAX_PIECES], ld_part[SLAB_MAX_PIECES];
+    bool ld_ok[SLAB_MAX_PIECES];
 #pragma unroll
-    for (int q = 0; q < C::MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
+    for (int q = 0; q < SLAB_MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
     const uint32_t ring_base = lds_offset_of(ring);
 
     // (re)build the torus tables and the loader constants for the dimensions in geo[]
@@ -337,23 +248,18 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         sA = sel3(ax_a, str0, str1, str2); sB = sel3(ax_b, str0, str1, str2); sM = sel3(ax_m, str0, str1, str2);
         layer_bytes = (uint32_t)(RA * RB * C::SLOT);
         pieces = (RA * RB * C::CH + SLAB_NW * 64 - 1) / (SLAB_NW * 64);
-        // TRILINEAR: N + 1 entries per axis, the last one repeats voxel N - 1 (the + 1 tap of the last cell is the clamped one)
-        constexpr int EX = TRI ? 1 : 0;
-        const int na = P.nx + P.ny + P.nz + 3 * EX;
+        const int na = P.nx + P.ny + P.nz;
         for (int e = (int)threadIdx.x; e < na; e += SLAB_THREADS) {
             int axis, i;
-            if (e < P.nx + EX) { axis = 0; i = min(e, P.nx - 1); }
-            else if (e < P.nx + P.ny + 2 * EX) { axis = 1; i = min(e - P.nx - EX, P.ny - 1); }
-            else { axis = 2; i = min(e - P.nx - P.ny - 2 * EX, P.nz - 1); }
+            if (e < P.nx) { axis = 0; i = e; } else if (e < P.nx + P.ny) { axis = 1; i = e - P.nx; } else { axis = 2; i = e - P.nx - P.ny; }
             const int R = axis == ax_a ? RA : (axis == ax_b ? RB : RZ);
             const uint32_t stride = axis == ax_a ? (uint32_t)C::SLOT : (axis == ax_b ? (uint32_t)(RA * C::SLOT) : layer_bytes);
-            // element offset inside the brick: x + 4y + 16z, or x + 5y + 20z in the apron copy's 5x4x4 bricks
-            const uint32_t in = TRI ? (uint32_t)(i & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u)) : (uint32_t)(i & 3) << (2 * axis);
-            const uint32_t inb = PK12 ? (3u * in) >> 1 : in * (uint32_t)sizeof(VoxelT);   // bytes (12-bit stream: floor(1.5 e), exact for the even y/z terms)
+            const uint32_t in = (uint32_t)(i & 3) << (2 * axis);          // element offset inside the brick: x + 4y + 16z
+            const uint32_t inb = PK12 ? (3u * in) >> 1 : in;               // bytes (12-bit stream: floor(1.5 e), exact for the even y/z terms)
             tab[e] = (TabT)((uint32_t)((i >> 2) % R) * stride + inb);
         }
 #pragma unroll
-        for (int q = 0; q < C::MAX_PIECES; q++) {
+        for (int q = 0; q < SLAB_MAX_PIECES; q++) {
             const int c = (q * SLAB_NW + (int)wave) * 64 + (int)lane;
             const int slot = c / C::CH;
             ld_part[q] = c - slot * C::CH;
@@ -370,7 +276,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     bool have_ring = false;              // the previous epoch left a consistent ring behind
     auto plan_epoch = [&](int ma, int sg, int ra, int rb, int rz, bool cold, int fcarry, int steps_left, uint4 &entry, int &f_after) -> bool {
         const int a_ = ma == 0 ? 1 : 0, b_ = ma == 2 ? 1 : 2;
-        const float MG = MGN;
+        const float MG = SLAB_MARGIN;
         auto lo = [&](int x, float j) { return sel3(x, Amin0, Amin1, Amin2) + j * sel3(x, dmn0, dmn1, dmn2) - MG; };
         auto hi = [&](int x, float j) { return sel3(x, Amax0, Amax1, Amax2) + j * sel3(x, dmx0, dmx1, dmx2) + MG; };
         auto blo = [&](int x, float j1, float j2) { const int b = (int)floorf(fminf(lo(x, j1), lo(x, j2))) >> 2; return clampi(b, 0, sel3(x, nbr0, nbr1, nbr2) - 1); };
@@ -420,16 +326,14 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     };
 
     // ---- one phase of the gathers: BATCH consecutive samples from the current position
-    constexpr int EXT = TRI ? 1 : 0;                                     // TRILINEAR tables hold N + 1 entries per axis
-    const TabT *tab_x = tab, *tab_y = tab + P.nx + EXT, *tab_z = tab + P.nx + P.ny + 2 * EXT;
-    // scaled texcoord (texcoord * dimension, per voxel axis) of the current position, which then advances by one step
-    // with the shader's additions
-    auto advance_scaled = [&](float &fx, float &fy, float &fz) {
+    const TabT *tab_x = tab, *tab_y = tab + P.nx, *tab_z = tab + P.nx + P.ny;
+    auto advance_index = [&](int &vi, int &vj, int &vk) {
         if (POW2) {
             const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
-            fx = ux; fy = uy; fz = uz;
+            float fx = ux, fy = uy, fz = uz;
             if (VIEW == 1) { fy = Sz - uz; fz = uy; }
             else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+            vi = (int)fx; vj = (int)fy; vk = (int)fz;
             Qx += dSx; Qy += dSy; Qz += dSz;
         } else {
             const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
@@ -439,47 +343,25 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             float tcx = ux, tcy = uy, tcz = uz;
             if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-            fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
+            vi = (int)(tcx * P.fdim[0]); vj = (int)(tcy * P.fdim[1]); vk = (int)(tcz * P.fdim[2]);
             qx += dsx; qy += dsy; qz += dsz;
         }
-    };
-    auto advance_index = [&](int &vi, int &vj, int &vk) {
-        float fx, fy, fz;
-        advance_scaled(fx, fy, fz);
-        vi = (int)fx; vj = (int)fy; vk = (int)fz;
     };
     // staged gathers come in two halves.  prepare(): positions of the phase's BATCH samples -> LDS offsets
     // through the torus tables (tables and positions do not depend on what the DMA is doing, so this runs
     // BEFORE the phase's barrier, overlapped with the other wavefronts).  fetch(): the ring reads proper, after
     // the barrier (two byte reads for the 12-bit stream: a 2-byte LDS read at an odd address is replayed for
-    // ~64 cycles on gfx950, tools/ubench/lds_slab.hip); v then holds the 16 stream bits around the voxel.
-    // TRILINEAR: NOFF = 4 tap addresses per sample -- the x0 taps of the (y0,z0), (y1,z0), (y0,z1), (y1,z1) corner
-    // pairs; the x1 tap of a pair is the next element of the apron slot -- and 3 lerp weights; u = max(f - 0.5, 0)
-    // gives cell 0 with weight 0 below the first voxel centre (== the shader's two clamped taps of voxel 0), the
-    // tables' duplicated last entry gives the clamped + 1 tap above the last one
-    constexpr int NOFF = TRI ? 4 : 1, NWT = TRI ? 3 : 1;
-    auto prepare = [&](uint32_t (&off)[BATCH * NOFF], float (&wt)[BATCH * NWT], uint32_t &nib) {
+    // ~64 cycles on gfx950, tools/ubench/lds_slab.hip); v then holds the 16 stream bits around the voxel
+    auto prepare = [&](uint32_t (&off)[BATCH], uint32_t &nib) {
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
-            if (TRI) {
-                float fx, fy, fz;
-                advance_scaled(fx, fy, fz);
-                const float ux = fmaxf(fx - 0.5f, 0.0f), uy = fmaxf(fy - 0.5f, 0.0f), uz = fmaxf(fz - 0.5f, 0.0f);
-                const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;        // == floor: u >= 0
-                wt[3 * u + 0] = ux - floorf(ux); wt[3 * u + 1] = uy - floorf(uy); wt[3 * u + 2] = uz - floorf(uz);
-                const uint32_t x0 = tab_x[i0], y0 = tab_y[j0], y1 = tab_y[j0 + 1], z0 = tab_z[k0], z1 = tab_z[k0 + 1];
-                off[4 * u + 0] = x0 + y0 + z0; off[4 * u + 1] = x0 + y1 + z0; off[4 * u + 2] = x0 + y0 + z1; off[4 * u + 3] = x0 + y1 + z1;
-            } else {
-                int vi, vj, vk;
-                advance_index(vi, vj, vk);
-                off[u] = (uint32_t)tab_x[vi] + (uint32_t)tab_y[vj] + (uint32_t)tab_z[vk];
-                if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);
-            }
+            int vi, vj, vk;
+            advance_index(vi, vj, vk);
+            off[u] = (uint32_t)tab_x[vi] + (uint32_t)tab_y[vj] + (uint32_t)tab_z[vk];
+            if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);
         }
     };
-    // (TRILINEAR reads its taps sample by sample inside consume(): 32 tap registers per phase would not fit)
-    auto fetch = [&](const uint32_t (&off)[BATCH * NOFF], uint32_t (&v)[BATCH]) {
-        if (TRI) return;
+    auto fetch = [&](const uint32_t (&off)[BATCH], uint32_t (&v)[BATCH]) {
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
 #if defined(VR_EXPERIMENTS) && defined(VR_X_NOGATHER)
@@ -488,28 +370,6 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             if (PK12) v[u] = (uint32_t)ring[off[u]] | ((uint32_t)ring[off[u] + 1] << 8);
             else v[u] = (uint32_t)ring[off[u]];
         }
-    };
-    auto fetch_taps = [&](const uint32_t *off4, uint32_t *tv) {        // the eight taps of one staged TRILINEAR sample
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const VoxelT *pair = reinterpret_cast<const VoxelT *>(ring + off4[t]);
-            tv[2 * t] = (uint32_t)pair[0]; tv[2 * t + 1] = (uint32_t)pair[1];
-        }
-    };
-    // TRILINEAR from the resident volume (head, tail, epochs that are not staged): the shader's clamped taps, literally
-    const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
-    auto taps_global = [&](float fx, float fy, float fz, uint32_t *tv, float &ax, float &ay, float &az) {
-        const float u = fx - 0.5f, v = fy - 0.5f, w = fz - 0.5f;
-        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
-        ax = u - fu; ay = v - fv; az = w - fw;
-        const int iu = (int)fu, iv = (int)fv, iw = (int)fw;
-        const int i0 = med3_i32(iu, 0, nxm1), i1 = med3_i32(iu + 1, 0, nxm1);
-        const int j0 = med3_i32(iv, 0, nym1), j1 = med3_i32(iv + 1, 0, nym1);
-        const int k0 = med3_i32(iw, 0, nzm1), k1 = med3_i32(iw + 1, 0, nzm1);
-        tv[0] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j0, k0)]; tv[1] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j0, k0)];
-        tv[2] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j1, k0)]; tv[3] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j1, k0)];
-        tv[4] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j0, k1)]; tv[5] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j0, k1)];
-        tv[6] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j1, k1)]; tv[7] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j1, k1)];
     };
     // not staged (an epoch whose footprint does not fit LDS): plain global loads of the voxels
     auto gather_global = [&](uint32_t (&v)[BATCH]) {
@@ -539,28 +399,6 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             c = v * a;                                                   // :131
         }
     };
-    // TRILINEAR: interpolation (x, then y, then z), window and classification of one sample from its eight taps
-    // tv[0..7] = (x0, x1) of the (y0,z0), (y1,z0), (y0,z1), (y1,z1) corners -- the generic kernel's operations
-    const float tf_scale = (float)(P.tf_len - 1);
-    auto shade = [&](const uint32_t *tv, float ax, float ay, float az, float &c, float &cg, float &cb, float &a) {
-        const float c000 = (float)tv[0], c100 = (float)tv[1], c010 = (float)tv[2], c110 = (float)tv[3];
-        const float c001 = (float)tv[4], c101 = (float)tv[5], c011 = (float)tv[6], c111 = (float)tv[7];
-        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-        float sv = c0 + az * (c1 - c0);
-        sv = fminf(fmaxf(sv, P.fmin), P.fmax);                           // never NaN here
-        sv = div_cert(sv - P.fmin, P.fden, P.rden);
-        if (MODE >= 2) {
-            int idx = (int)(sv * tf_scale + 0.5f);                       // sv in [0, 1]: truncation == floor
-            idx = med3_i32(idx, 0, P.tf_len - 1);
-            const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
-            c = q.x; cg = q.y; cb = q.z; a = q.w;
-        } else {
-            a = sv * P.alpha_scale;
-            c = sv * a;
-        }
-    };
     auto accumulate = [&](float c, float cg, float cb, float a) {
         if (MODE == 1) {
             if (da < a) da = a;
@@ -584,18 +422,11 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
         else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
         if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
+        const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
+        const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
+        const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
         float c, cg = 0.0f, cb = 0.0f, a;
-        if (TRI) {
-            uint32_t tv[8];
-            float ax, ay, az;
-            taps_global(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], tv, ax, ay, az);
-            shade(tv, ax, ay, az, c, cg, cb, a);
-        } else {
-            const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
-            const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
-            const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
-            classify((uint32_t)vol[VoxelAddr<1, true>::at(P, vi, vj, vk)], c, cg, cb, a);
-        }
+        classify((uint32_t)vol[VoxelAddr<1, true>::at(P, vi, vj, vk)], c, cg, cb, a);
         accumulate(c, cg, cb, a);
         x += stx; y += sty; z += stz;
         return false;
@@ -609,22 +440,14 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         }
     }
     // compositing of one phase; returns true when the ray terminated (batch early-termination, see the fast kernel)
-    // (TRILINEAR: v is unused, the taps of sample u are read from the ring at off[4u .. 4u+3] right before they are shaded)
-    auto consume = [&](const uint32_t (&v)[BATCH], const uint32_t (&off)[BATCH * NOFF], const float (&wt)[BATCH * NWT], uint32_t nib, bool raw) -> bool {
+    auto consume = [&](const uint32_t (&v)[BATCH], uint32_t nib, bool raw) -> bool {
         float c[BATCH], cg[BATCH], cb[BATCH], a[BATCH];
         const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
         float da_last = 0.0f;
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
-            cg[u] = cb[u] = 0.0f;
-            if (TRI) {
-                uint32_t tv[8];
-                fetch_taps(&off[4 * u], tv);
-                shade(tv, wt[3 * u + 0], wt[3 * u + 1], wt[3 * u + 2], c[u], cg[u], cb[u], a[u]);
-            } else {
-                const uint32_t texel = (PK12 && !raw) ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u];
-                classify(texel, c[u], cg[u], cb[u], a[u]);
-            }
+            const uint32_t texel = (PK12 && !raw) ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u];
+            classify(texel, c[u], cg[u], cb[u], a[u]);
         }
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
@@ -641,22 +464,6 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         }
         return da >= 0.95f;
     };
-    // TRILINEAR phase of an epoch that is not staged: the shader's loop on global taps, sample by sample (the positions are
-    // inside the safe prefix, so the bounds tests cannot fire); true = the ray terminated
-    auto march_global_tri = [&]() -> bool {
-#pragma unroll 1
-        for (int u = 0; u < BATCH; u++) {
-            if (da >= 0.95f) return true;
-            float fx, fy, fz, ax, ay, az, c, cg = 0.0f, cb = 0.0f, a;
-            uint32_t tv[8];
-            advance_scaled(fx, fy, fz);
-            taps_global(fx, fy, fz, tv, ax, ay, az);
-            shade(tv, ax, ay, az, c, cg, cb, a);
-            accumulate(c, cg, cb, a);
-            i++;
-        }
-        return false;
-    };
 
     // ---- the phase loop: ONE barrier per phase (it orders "every wavefront has finished reading the layers
     // of phase p-1" before their slots are overwritten, and "the pieces each wavefront waited for have landed"
@@ -666,8 +473,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
     bool fin = nb == 0 || head_ended;
     int b = 0;                                   // phases this ray has marched (== the phase counter while it is live)
     bool epoch_staged = false;
-    uint32_t off[BATCH * NOFF] = {};             // prepared LDS offsets of the next phase's samples
-    float wt[BATCH * NWT] = {};                  // TRILINEAR: their lerp weights
+    uint32_t off[BATCH] = {};                    // prepared LDS offsets of the next phase's samples
     uint32_t nib = 0;
     bool prepared = false;
     uint4 entry_next = make_uint4(0u, 0u, 0u, 0u);   // the next phase's plan entry, read before the barrier
@@ -713,7 +519,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                     constexpr int HORIZON_EPOCHS = 1;
 #endif
                     const float horizon = fminf((float)(BATCH * SLAB_EPOCH * HORIZON_EPOCHS), (float)steps_left) + (float)(BATCH * SLAB_LA + 8);
-                    auto span = [&](int x) { return (sel3(x, Amax0, Amax1, Amax2) - sel3(x, Amin0, Amin1, Amin2)) + horizon * (sel3(x, dmx0, dmx1, dmx2) - sel3(x, dmn0, dmn1, dmn2)) + 2.0f * MGN; };
+                    auto span = [&](int x) { return (sel3(x, Amax0, Amax1, Amax2) - sel3(x, Amin0, Amin1, Amin2)) + horizon * (sel3(x, dmx0, dmx1, dmx2) - sel3(x, dmn0, dmn1, dmn2)) + 2.0f * SLAB_MARGIN; };
                     status = 2;
                     if (sg != 0 && vslow >= 0.125f) {
                         const int a_ = ma == 0 ? 1 : 0, b_ = ma == 2 ? 1 : 2;
@@ -771,10 +577,10 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                 int lz = (int)(ew & 0xffu);
                 const bool cold = (ew & 0x100u) != 0u;
                 // this lane's brick inside the rectangle, per piece (the same for every layer of the entry)
-                uint32_t rel[C::MAX_PIECES];
-                bool ok[C::MAX_PIECES];
+                uint32_t rel[SLAB_MAX_PIECES];
+                bool ok[SLAB_MAX_PIECES];
 #pragma unroll
-                for (int q = 0; q < C::MAX_PIECES; q++) {
+                for (int q = 0; q < SLAB_MAX_PIECES; q++) {
                     int oa = ld_ta[q] - la, ob = ld_tb[q] - lb;
                     if (oa < 0) oa += RA;
                     if (ob < 0) ob += RB;
@@ -784,7 +590,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
                 for (int l = 0; l < n; l++) {
                     const uint32_t layer_idx = (uint32_t)(first_b + sgn * l) * sM;   // uniform
 #pragma unroll
-                    for (int q = 0; q < C::MAX_PIECES; q++) {
+                    for (int q = 0; q < SLAB_MAX_PIECES; q++) {
                         if (q >= pieces) break;
                         if (__any(ok[q] ? 1 : 0)) {
                             if (ok[q]) {
@@ -817,16 +623,13 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
             bool term;
             if (epoch_staged) {
                 uint32_t v[BATCH];
-                if (!prepared) prepare(off, wt, nib);
+                if (!prepared) prepare(off, nib);
                 fetch(off, v);
-                term = consume(v, off, wt, nib, false);
-            } else if (TRI) {
-                term = march_global_tri();
-                asm volatile("" ::: "memory");
+                term = consume(v, nib, false);
             } else {
                 uint32_t v[BATCH];
                 gather_global(v);
-                term = consume(v, off, wt, 0u, true);
+                term = consume(v, 0u, true);
                 asm volatile("" ::: "memory");
             }
             if (term) { done = true; fin = true; }
@@ -837,7 +640,7 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
         prepared = false;
         if (epoch_staged && pe != SLAB_EPOCH - 1) {
             entry_next = plan[pe + 1];
-            if (!fin) { prepare(off, wt, nib); prepared = true; }
+            if (!fin) { prepare(off, nib); prepared = true; }
         }
         // ---- what the next phase reads must have landed before its barrier
 #if !(defined(VR_EXPERIMENTS) && defined(VR_X_NOWAIT))
@@ -868,32 +671,31 @@ __global__ __launch_bounds__(SLAB_THREADS, 4) void raymarch_slab_kernel(const Fr
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename VoxelT, bool PK12, int DIVTC, int VIEW, bool POW2, bool NOCLAMP, int MODE, bool TRI>
+template <typename VoxelT, bool PK12, int DIVTC, int VIEW, bool POW2, bool NOCLAMP, int MODE>
 static hipError_t launch_slab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                               uint32_t *spp, hipStream_t st)
 {
-    // what is staged: the apron copy (TRILINEAR), the 12-bit packed copy, or the bricked volume itself (u8)
-    const void *src = TRI ? L.apron : (PK12 ? L.packed12 : vol);
-    hipLaunchKernelGGL((raymarch_slab_kernel<VoxelT, PK12, DIVTC, VIEW, POW2, NOCLAMP, MODE, TRI>), dim3(L.tile_table_blocks),
-                       dim3(SLAB_THREADS), 0, st, P, (const VoxelT *)vol, (const uint8_t *)src, tf, fb, spp, L.tile_table);
+    hipLaunchKernelGGL((raymarch_slab_kernel<VoxelT, PK12, DIVTC, VIEW, POW2, NOCLAMP, MODE>), dim3(L.tile_table_blocks),
+                       dim3(SLAB_THREADS), 0, st, P, (const VoxelT *)vol, (const uint8_t *)(PK12 ? L.packed12 : vol), tf, fb, spp,
+                       L.tile_table);
     return hipGetLastError();
 }
 
-template <typename VoxelT, bool PK12, int VIEW, int MODE, bool TRI>
+template <typename VoxelT, bool PK12, int VIEW, int MODE>
 static hipError_t dispatch_slab3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                  uint32_t *spp, hipStream_t st)
 {
-    const bool noclamp = !TRI && MODE == 0 && L.lut_noclamp != 0;       // like the fast kernel: headline mode only
+    const bool noclamp = MODE == 0 && L.lut_noclamp != 0;               // like the fast kernel: headline mode only
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-#define VR_SLAB(TC, P2) (noclamp ? launch_slab<VoxelT, PK12, TC, VIEW, P2, !TRI && MODE == 0, MODE, TRI>(P, L, vol, tf, fb, spp, st) \
-                                 : launch_slab<VoxelT, PK12, TC, VIEW, P2, false, MODE, TRI>(P, L, vol, tf, fb, spp, st))
+#define VR_SLAB(TC, P2) (noclamp ? launch_slab<VoxelT, PK12, TC, VIEW, P2, MODE == 0, MODE>(P, L, vol, tf, fb, spp, st) \
+                                 : launch_slab<VoxelT, PK12, TC, VIEW, P2, false, MODE>(P, L, vol, tf, fb, spp, st))
     if (L.divmode_tc == DIV_CERT) return VR_SLAB(DIV_CERT, false);
     if (pow2) return VR_SLAB(DIV_UNIT, true);
     return VR_SLAB(DIV_UNIT, false);
 #undef VR_SLAB
 }
 
-template <typename VoxelT, bool PK12, bool TRI>
+template <typename VoxelT, bool PK12>
 static hipError_t dispatch_slab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                 uint32_t *spp, hipStream_t st)
 {
@@ -901,10 +703,10 @@ static hipError_t dispatch_slab(const FrameParams &P, const LaunchConfig &L, con
     const int mode = (L.mip ? 1 : 0) + (P.tf_len > 1 ? 2 : 0);
 #define VR_SLAB_M(VW)                                                                                          \
     switch (mode) {                                                                                            \
-    case 0: return dispatch_slab3<VoxelT, PK12, VW, 0, TRI>(P, L, vol, tf, fb, spp, st);                       \
-    case 1: return dispatch_slab3<VoxelT, PK12, VW, 1, TRI>(P, L, vol, tf, fb, spp, st);                       \
-    case 2: return dispatch_slab3<VoxelT, PK12, VW, 2, TRI>(P, L, vol, tf, fb, spp, st);                       \
-    default: return dispatch_slab3<VoxelT, PK12, VW, 3, TRI>(P, L, vol, tf, fb, spp, st);                      \
+    case 0: return dispatch_slab3<VoxelT, PK12, VW, 0>(P, L, vol, tf, fb, spp, st);                            \
+    case 1: return dispatch_slab3<VoxelT, PK12, VW, 1>(P, L, vol, tf, fb, spp, st);                            \
+    case 2: return dispatch_slab3<VoxelT, PK12, VW, 2>(P, L, vol, tf, fb, spp, st);                            \
+    default: return dispatch_slab3<VoxelT, PK12, VW, 3>(P, L, vol, tf, fb, spp, st);                           \
     }
     if (view == 0) { VR_SLAB_M(0) }
     if (view == 1) { VR_SLAB_M(1) }
@@ -912,7 +714,6 @@ static hipError_t dispatch_slab(const FrameParams &P, const LaunchConfig &L, con
 #undef VR_SLAB_M
 }
 
-// translation units: 0 = NEAREST u8, 1 = NEAREST 12-bit packed copy, 2 = TRILINEAR u8, 3 = TRILINEAR u16; -1 = all
 #ifndef VR_SLAB_TU
 #define VR_SLAB_TU -1
 #endif
@@ -920,28 +721,14 @@ static hipError_t dispatch_slab(const FrameParams &P, const LaunchConfig &L, con
 hipError_t launch_raymarch_slab_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                    uint32_t *spp, hipStream_t st)
 {
-    return dispatch_slab<uint8_t, false, false>(P, L, vol, tf, fb, spp, st);
+    return dispatch_slab<uint8_t, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
 #if VR_SLAB_TU == 1 || VR_SLAB_TU == -1
 hipError_t launch_raymarch_slab_pk12(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                      uint32_t *spp, hipStream_t st)
 {
-    return dispatch_slab<uint16_t, true, false>(P, L, vol, tf, fb, spp, st);
-}
-#endif
-#if VR_SLAB_TU == 2 || VR_SLAB_TU == -1
-hipError_t launch_raymarch_slab_tri_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                       uint32_t *spp, hipStream_t st)
-{
-    return dispatch_slab<uint8_t, false, true>(P, L, vol, tf, fb, spp, st);
-}
-#endif
-#if VR_SLAB_TU == 3 || VR_SLAB_TU == -1
-hipError_t launch_raymarch_slab_tri_u16(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                        uint32_t *spp, hipStream_t st)
-{
-    return dispatch_slab<uint16_t, false, true>(P, L, vol, tf, fb, spp, st);
+    return dispatch_slab<uint16_t, true>(P, L, vol, tf, fb, spp, st);
 }
 #endif
 

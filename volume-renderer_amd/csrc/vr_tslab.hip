@@ -1,0 +1,585 @@
+// vr_tslab.hip -- TRILINEAR ray-march with the volume's bricks staged in LDS, for gfx950 (MI355X / CDNA4).
+//
+// Same arithmetic as every other trilinear path of this library (GL's linear rule on the shader's sample positions,
+// VolumeRenderer.cs:121 with the filter state of src/RendererCore.cpp:414-415; fixed lerp order x, y, z as in
+// oracle/vr_oracle.c; iterative position accumulation; checked head + safe prefix + checked tail, vr_device.h).
+// What changes is where the prefix's eight taps per sample come from, and in which ORDER a workgroup's rays advance.
+//
+// Why: the batched trilinear kernel (vr_kernels.hip) issues 4-8 scattered global gathers per sample; on gfx950 the
+// vector L1 pays 4 cycles per distinct cache line per gather instruction, and that alone costs more than the kernel's
+// arithmetic (round 2: 843 M tag look-ups, 1.93 ms on the 1024^3 workload).  Here a workgroup (8 wavefronts = a 32x16-pixel
+// tile) keeps the bricks its rays are crossing in LDS and reads the taps with ds_read_u16 / ds_read_u8:
+//   * staged source = the APRON copy of the volume (vr_device.h: every 4x4x4 brick stored as 5x4x4, the x neighbours of
+//     its last column included, clamped at the volume's faces): a slot is 160 B (u16) / 80 B (u8); the x1 tap of every
+//     corner pair is the x0 tap's next element (a ds_read immediate offset), so a sample needs FOUR tap addresses --
+//     X[i0] + Y[j0|j0+1] + Z[k0|k0+1] -- out of five look-ups in per-axis torus tables; 160-byte slots also spread the
+//     bricks of one sheet over the LDS banks (128-byte slots: 2-3x the conflicts, tools/ubench/lds_taps.hip);
+//   * bricks arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR staging), whole brick
+//     LAYERS along the tile's major axis m (the voxel axis the rays advance along fastest); a layer lives in slot
+//     (i mod RA, j mod RB, L mod RZ) of a torus, so a voxel's LDS offset stays a sum of three table entries;
+//   * LAYER-SYNCHRONOUS marching: phase p of the workgroup is brick layer L_p = L_0 + sgn * p.  In phase p every ray
+//     takes exactly the samples whose cell (k0 = floor(f_m - 0.5)) lies in layer L_p -- 4-5 samples at one voxel per
+//     step, as many as it takes for oblique rays -- then waits at ONE barrier.  All rays of the tile therefore read
+//     layers L_p and L_p + 1 only, whatever their directions: the ring needs 2 live layers + 1-2 being loaded (RZ = 3
+//     or 4) instead of the 5-6 a sample-synchronous scheme needs, and an oblique view costs one layer-thickness of
+//     drift in the footprint, not a whole oblique sheet (round 2's sample-synchronous NEAREST kernel, vr_slab.hip,
+//     staged 4 % of an off-axis frame; the first trilinear build on it fell back to global taps in 27 % of its epochs);
+//   * the footprint of layer L is CLOSED FORM: in voxel coordinates a ray is the line E + t * G (E = eye, one G per
+//     pixel), and at the plane f_m = c its other two coordinates are fractional-linear in the pixel position, so over
+//     the tile's pixel rectangle their extremes sit at the four corner pixels.  Thread L evaluates the four corner
+//     rays at the two planes bounding layer L's samples and publishes the brick rectangle in LDS: no anchors, no
+//     epochs, no per-phase reductions.  Margins: half a voxel for the taps, 1/16 voxel + the rounding drift of the
+//     iterated positions (k * 2^-23 * N voxels) for the difference between the lines and the marched positions;
+//   * no clamps in the prefix: u = max(f - 0.5, 0) makes the low edge exact (cell 0 with weight 0 == the shader's two
+//     clamped taps of voxel 0), the high edge is the apron column (x) or a duplicated last table entry (y, z).
+// A tile whose corner rays disagree on the major axis or its sign, or whose layers do not fit the ring three deep,
+// marches its prefix on global taps (same arithmetic, slower); head and tail always do.
+// Correctness does not depend on the rectangles being tight, only on their being supersets; the parity tests compare
+// whole frames bit for bit against the oracle and the other trilinear kernels.
+//
+// No MFMA: eight taps, seven lerps and a 5-flop recurrence per sample.
+#include "vr_device.h"
+#include "vr_lds_dma.h"
+
+namespace vr {
+
+constexpr int TS_NW = 8, TS_THREADS = 64 * TS_NW;         // one 32x16-pixel tile per workgroup
+#if defined(VR_EXPERIMENTS) && defined(VR_X_LDSKB)
+constexpr int TS_LDS_BYTES = VR_X_LDSKB * 1024 - 512;
+#else
+constexpr int TS_LDS_BYTES = 80 * 1024 - 512;             // two workgroups per CU (160 KiB)
+#endif
+constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
+constexpr int TS_MAX_PIECES = 3;                          // 1-KiB DMA pieces per wavefront per layer
+constexpr int TS_MAX_LAYERS = 1536;                       // brick layers along the major axis the plan can hold
+constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
+
+template <typename VoxelT, int MODE>
+struct TslabCfg {
+    static constexpr int SLOT = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // 80 B (u8) / 160 B (u16)
+    static constexpr int CH = SLOT / 16;                                          // 16-byte chunks per slot
+    static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
+    static constexpr int TAB_AXES = sizeof(VoxelT) == 1 ? 6144 : 3072;            // nx + ny + nz
+    static constexpr int TAB_ENTRIES = TAB_AXES + 4;                              // + one duplicated last entry per axis
+    static constexpr int MISC_BYTES = 512;
+    // ring + plan; torus tables are 16-bit ELEMENT offsets, so the region may reach 64 Ki elements
+    static constexpr int REGION_RAW = TS_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES;
+    static constexpr int REGION = (REGION_RAW > 65535 * (int)sizeof(VoxelT) ? 65535 * (int)sizeof(VoxelT) : REGION_RAW) / 16 * 16;
+    static constexpr int LAYER_SLOTS_MAX = TS_MAX_PIECES * TS_NW * 64 / CH;
+};
+
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
+__global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const FrameParams P,
+                                                                       const VoxelT *__restrict__ vol,
+                                                                       const uint8_t *__restrict__ src,
+                                                                       const float4 *__restrict__ tf,
+                                                                       float4 *__restrict__ fb,
+                                                                       uint32_t *__restrict__ spp,
+                                                                       const uint32_t *__restrict__ tile_table)
+{
+    using C = TslabCfg<VoxelT, MODE>;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
+    __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
+    __shared__ uint16_t tab[C::TAB_ENTRIES];
+    __shared__ float corner[5][4];              // rows 0..3: G of the corner rays, row 4: E (voxel coordinates)
+    __shared__ int red[8];                      // 0: min first progress, 1: max last progress, 2: max prefix length, 3 / 4: max rectangle extents
+    static_assert(sizeof(corner) + sizeof(red) <= C::MISC_BYTES, "LDS budget");
+
+    const uint32_t t = tile_table[blockIdx.x];
+    if (t == 0xffffffffu) return;                                       // padding block
+    const unsigned tx = t & 0xffffu, ty = t >> 16;
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lx = (int)(tx * kFastTileW + (wave & 3u) * 8u + (lane & 7u));
+    const int ly = (int)(ty * kFastTileH + (wave >> 2) * 8u + (lane >> 3));
+    int px = lx, py;
+    if (P.stripe_count > 1) {
+        const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (st * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    const bool in_image = !(px >= P.col_lim || py >= P.row_lim || py >= P.row_end);
+
+    // every thread has a ray (the tile's corner pixels bound the footprint even when they lie outside the image)
+    const Ray ray = compute_ray(P, (float)px + 0.5f, (float)py + 0.5f);
+    float t_min = 0.0f, t_max = 0.0f;
+    const bool hit = in_image && intersect_ray_aabb(P, ray, t_min, t_max);
+    if (!__syncthreads_or(hit ? 1 : 0)) {                               // no ray of the tile enters the volume
+        if (in_image) {
+            const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+            store_pixel(P, fb, pix, 0.0f, 0.0f, 0.0f, 0.0f);
+            if (spp) spp[pix] = 0u;
+        }
+        return;
+    }
+    if (MODE >= 2) {                                                     // 256 premultiplied RGBA entries, as in the fast kernel
+        for (int e = (int)threadIdx.x; e < P.tf_len; e += TS_THREADS) {
+            const float4 q = tf[e];
+            const float a = q.w * P.alpha_scale;
+            if (MODE == 3) { lut[4 * e + 0] = q.x * P.alpha_scale; lut[4 * e + 1] = q.y * P.alpha_scale; lut[4 * e + 2] = q.z * P.alpha_scale; }
+            else { lut[4 * e + 0] = q.x * a; lut[4 * e + 1] = q.y * a; lut[4 * e + 2] = q.z * a; }
+            lut[4 * e + 3] = a;
+        }
+    }
+
+    float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f;
+    const float EPSILON = 0.000001f;
+    const float sx = ray.ox + ray.dx * t_min, sy = ray.oy + ray.dy * t_min, sz = ray.oz + ray.dz * t_min;
+    float qx = sx + ray.dx * EPSILON, qy = sy + ray.dy * EPSILON, qz = sz + ray.dz * EPSILON;
+    const float dsx = ray.dx * P.step, dsy = ray.dy * P.step, dsz = ray.dz * P.step;
+    // checked head (vr_device.h: head_steps): positions stepped here, sampled through the checked loop below
+    const float hqx = qx, hqy = qy, hqz = qz;
+    const int head = hit ? head_steps(P, qx, qy, qz, dsx, dsy, dsz) : 0;
+    for (int h = 0; h < head; h++) { qx += dsx; qy += dsy; qz += dsz; }
+    const int k_safe = hit ? safe_prefix_length(P, qx, qy, qz, dsx, dsy, dsz, P.max_steps - head) : 0;
+
+    // marching units: voxels for POW2 (exact, see raymarch_fast_kernel), box units otherwise
+    const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
+    float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
+    const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
+    const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+
+    // voxel coordinates (floats, per voxel axis i/j/k) of a box position: an affine map, exact for POW2 and within a
+    // few ulp otherwise -- only the load plan uses it, behind its margins
+    auto voxel_float = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
+        const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
+        const float uz = 1.0f - (az + P.half[2]) * P.rext[2];
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+        fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
+    };
+    // scaled texcoord (texcoord * dimension per voxel axis) of the CURRENT position, the shader's operations
+    auto scaled_here = [&](float &fx, float &fy, float &fz) {
+        if (POW2) {
+            const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+            fx = ux; fy = uy; fz = uz;
+            if (VIEW == 1) { fy = Sz - uz; fz = uy; }
+            else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+        } else {
+            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
+            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
+            uz = 1.0f - uz;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
+        }
+    };
+    auto advance = [&]() {
+        if (POW2) { Qx += dSx; Qy += dSy; Qz += dSz; }
+        else { qx += dsx; qy += dsy; qz += dsz; }
+    };
+
+    // ---- TRILINEAR from the resident volume (head, tail, tiles that are not staged): the shader's clamped taps, literally
+    const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
+    auto taps_global = [&](float fx, float fy, float fz, uint32_t *tv, float &ax, float &ay, float &az) {
+        const float u = fx - 0.5f, v = fy - 0.5f, w = fz - 0.5f;
+        const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+        ax = u - fu; ay = v - fv; az = w - fw;
+        const int iu = (int)fu, iv = (int)fv, iw = (int)fw;
+        const int i0 = med3_i32(iu, 0, nxm1), i1 = med3_i32(iu + 1, 0, nxm1);
+        const int j0 = med3_i32(iv, 0, nym1), j1 = med3_i32(iv + 1, 0, nym1);
+        const int k0 = med3_i32(iw, 0, nzm1), k1 = med3_i32(iw + 1, 0, nzm1);
+        tv[0] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j0, k0)]; tv[1] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j0, k0)];
+        tv[2] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j1, k0)]; tv[3] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j1, k0)];
+        tv[4] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j0, k1)]; tv[5] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j0, k1)];
+        tv[6] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i0, j1, k1)]; tv[7] = (uint32_t)vol[VoxelAddr<1, true>::at(P, i1, j1, k1)];
+    };
+    // interpolation (x, then y, then z), window and classification of one sample from its eight taps
+    // tv[0..7] = (x0, x1) of the (y0,z0), (y1,z0), (y0,z1), (y1,z1) corners -- the generic kernel's operations
+    const float tf_scale = (float)(P.tf_len - 1);
+    auto shade = [&](const uint32_t *tv, float ax, float ay, float az, float &c, float &cg, float &cb, float &a) {
+        const float c000 = (float)tv[0], c100 = (float)tv[1], c010 = (float)tv[2], c110 = (float)tv[3];
+        const float c001 = (float)tv[4], c101 = (float)tv[5], c011 = (float)tv[6], c111 = (float)tv[7];
+        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+        float sv = c0 + az * (c1 - c0);
+        sv = fminf(fmaxf(sv, P.fmin), P.fmax);                           // never NaN here
+        sv = div_cert(sv - P.fmin, P.fden, P.rden);
+        if (MODE >= 2) {
+            int idx = (int)(sv * tf_scale + 0.5f);                       // sv in [0, 1]: truncation == floor
+            idx = med3_i32(idx, 0, P.tf_len - 1);
+            const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
+            c = q.x; cg = q.y; cb = q.z; a = q.w;
+        } else {
+            a = sv * P.alpha_scale;
+            c = sv * a;
+        }
+    };
+    auto accumulate = [&](float c, float cg, float cb, float a) {
+        if (MODE == 1) {
+            if (da < a) da = a;
+        } else if (MODE == 3) {
+            if (da < a) { drgb = c; dg = cg; db = cb; da = a; }
+        } else {
+            const float om = 1.0f - da;
+            drgb += c * om;
+            if (MODE == 2) { dg += cg * om; db += cb * om; }
+            da += a * om;
+        }
+    };
+    int i = 0;
+    // one iteration of the shader's loop at (x, y, z), literally; true = the loop ends here
+    auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
+        const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
+        const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
+        float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
+        uz = 1.0f - uz;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+        if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
+        uint32_t tv[8];
+        float ax, ay, az, c, cg = 0.0f, cb = 0.0f, a;
+        taps_global(tcx * P.fdim[0], tcy * P.fdim[1], tcz * P.fdim[2], tv, ax, ay, az);
+        shade(tv, ax, ay, az, c, cg, cb, a);
+        accumulate(c, cg, cb, a);
+        x += stx; y += sty; z += stz;
+        return false;
+    };
+    bool head_ended = false;
+    if (head > 0) {                                                      // samples 0 .. head - 1
+        float x = hqx, y = hqy, z = hqz;
+        for (int h = 0; h < head && !head_ended; h++) {
+            if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) head_ended = true;
+            else i++;
+        }
+    }
+    bool done = head_ended;
+    int rem = head_ended ? 0 : k_safe;                                   // prefix samples still to take
+
+    // ================================================================== the tile's load plan
+    // corner rays in voxel coordinates: line E + t * G
+    const bool is_corner = (wave == 0 && lane == 0) || (wave == 3 && lane == 7) || (wave == 4 && lane == 56) || (wave == 7 && lane == 63);
+    if (is_corner) {
+        const int cidx = (wave >= 4 ? 2 : 0) + ((wave & 3u) == 3u ? 1 : 0);
+        float ex, ey, ez, gx, gy, gz;
+        voxel_float(ray.ox, ray.oy, ray.oz, ex, ey, ez);
+        voxel_float(ray.ox + ray.dx, ray.oy + ray.dy, ray.oz + ray.dz, gx, gy, gz);
+        corner[cidx][0] = gx - ex; corner[cidx][1] = gy - ey; corner[cidx][2] = gz - ez;
+        if (cidx == 0) { corner[4][0] = ex; corner[4][1] = ey; corner[4][2] = ez; }
+    }
+    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; }
+    __syncthreads();
+    float G[4][3], E[3];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) G[c][a] = uniform_f(corner[c][a]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) E[a] = uniform_f(corner[4][a]);
+    // major axis: where corner 0 advances fastest; all four corners must agree on its sign and not graze it
+    int ax_m = 2;
+    {
+        const float g0 = fabsf(G[0][0]), g1 = fabsf(G[0][1]), g2 = fabsf(G[0][2]);
+        ax_m = (g0 >= g1 && g0 >= g2) ? 0 : (g1 >= g2 ? 1 : 2);
+    }
+    const int ax_a = ax_m == 0 ? 1 : 0, ax_b = ax_m == 2 ? 1 : 2;
+    bool stage = true;
+    int sgn = 1;
+    {
+        bool pos = true, neg = true;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]);
+            const float gmax = fmaxf(fmaxf(fabsf(G[c][0]), fabsf(G[c][1])), fabsf(G[c][2]));
+            pos = pos && gm >= TS_MIN_AXIS * gmax && gm > 0.0f;
+            neg = neg && -gm >= TS_MIN_AXIS * gmax && gm < 0.0f;
+        }
+        stage = pos || neg;
+        sgn = neg ? -1 : 1;
+    }
+    const int nbr0 = P.bnx, nbr1 = P.bny, nbr2 = P.bnz;                // bricks per voxel axis
+    const int nbr_m = sel3(ax_m, nbr0, nbr1, nbr2), nbr_a = sel3(ax_a, nbr0, nbr1, nbr2), nbr_b = sel3(ax_b, nbr0, nbr1, nbr2);
+    const int ndim_m = sel3(ax_m, P.nx, P.ny, P.nz);
+    if (nbr_m > TS_MAX_LAYERS) stage = false;
+    // layer (along m) of the cell a position's taps start in: floor(max(f_m - 0.5, 0)) >> 2
+    auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> 2; };
+    {
+        // first / last layer of this ray's prefix in progress coordinates (sgn * layer), prefix length: workgroup extremes
+        if (rem > 0) {
+            float fx, fy, fz;
+            scaled_here(fx, fy, fz);
+            const int l_first = layer_of(sel3(ax_m, fx, fy, fz));
+            float lx2, ly2, lz2;
+            const float kk = (float)(rem - 1);
+            voxel_float((POW2 ? Qx / Sx : qx) + kk * dsx, (POW2 ? Qy / Sy : qy) + kk * dsy, (POW2 ? Qz / Sz : qz) + kk * dsz, lx2, ly2, lz2);
+            const int l_last = layer_of(sel3(ax_m, lx2, ly2, lz2));
+            atomicMin(&red[0], sgn * l_first);
+            atomicMax(&red[1], sgn * l_last + 1);                        // + 1: the closed form may sit one layer short
+            atomicMax(&red[2], rem);
+        }
+    }
+    __syncthreads();
+    const int c_first = uniform_i(red[0]), kmax = uniform_i(red[2]);
+    int c_last = uniform_i(red[1]);
+    const bool any_prefix = kmax > 0;
+    // progress coordinates stay inside the volume
+    c_last = sgn > 0 ? min(c_last, nbr_m - 1) : min(c_last, 0);
+    const int n_phases = any_prefix ? c_last - c_first + 1 : 0;
+    const int L0 = sgn * c_first;                                        // layer of phase 0
+    // margin between the corner lines and the marched positions: rounding drift of k iterated additions (<= k * 2^-24 * |pos|
+    // per axis, |pos| in voxels <= N) + the evaluation error of the lines themselves (eye far away: |E| * 2^-22)
+    const float nmax = fmaxf(fmaxf(P.fdim[0], P.fdim[1]), P.fdim[2]);
+    const float emax = fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fabsf(E[2]));
+    const float delta = TS_MARGIN + (float)kmax * 1.2e-7f * nmax + emax * 2.4e-7f;
+    int plan_bytes = (nbr_m * 8 + 15) & ~15;
+    if (plan_bytes > C::REGION / 2) stage = false;
+    uint2 *plan = reinterpret_cast<uint2 *>(ring + (stage ? C::REGION - plan_bytes : 0));
+    if (stage && any_prefix) {
+        for (int L = (int)threadIdx.x; L < nbr_m; L += TS_THREADS) {
+            const float c_lo = (float)(4 * L) - 0.5f - delta, c_hi = (float)(4 * L) + 4.5f + delta;
+            float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]), ga = sel3(ax_a, G[c][0], G[c][1], G[c][2]), gb = sel3(ax_b, G[c][0], G[c][1], G[c][2]);
+                const float em = sel3(ax_m, E[0], E[1], E[2]), ea = sel3(ax_a, E[0], E[1], E[2]), eb = sel3(ax_b, E[0], E[1], E[2]);
+                const float t1 = (c_lo - em) / gm, t2 = (c_hi - em) / gm;
+                const float a1 = ea + t1 * ga, a2 = ea + t2 * ga, b1 = eb + t1 * gb, b2 = eb + t2 * gb;
+                amin = fminf(amin, fminf(a1, a2)); amax = fmaxf(amax, fmaxf(a1, a2));
+                bmin = fminf(bmin, fminf(b1, b2)); bmax = fmaxf(bmax, fmaxf(b1, b2));
+            }
+            // taps: voxels floor(f - 0.5) and + 1 per axis
+            const float big = 1.0e9f;
+            const int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
+            const int hi_a = clampi((int)floorf(fmaxf(fminf(amax + 0.5f + delta, big), -big)) >> 2, 0, nbr_a - 1);
+            const int lo_b = clampi((int)floorf(fmaxf(fminf(bmin - 0.5f - delta, big), -big)) >> 2, 0, nbr_b - 1);
+            const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
+            const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
+            plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
+            const int cL = sgn * L;
+            if (cL >= c_first - 1 && cL <= c_last + 3) {                 // layers some phase reads (L_p and L_p + 1) or prefetches
+                atomicMax(&red[3], dda);
+                atomicMax(&red[4], ddb);
+            }
+        }
+    }
+    __syncthreads();
+    const int RA = uniform_i(red[3]) + 1, RB = uniform_i(red[4]) + 1;
+    const int slots_avail = (C::REGION - plan_bytes) / C::SLOT;
+    if (RA * RB > C::LAYER_SLOTS_MAX || RA * RB * 3 > slots_avail || RA > 255 || RB > 255) stage = false;
+    const int RZ = stage ? min(slots_avail / (RA * RB), 4) : 1;
+    const int LA = RZ - 2;                                               // phases of prefetch distance: 1 or 2
+    const uint32_t layer_bytes = (uint32_t)(RA * RB * C::SLOT);
+    const int pieces = (RA * RB * C::CH + TS_THREADS - 1) / TS_THREADS;
+    const uint32_t str0 = 1u, str1 = (uint32_t)P.bnx, str2 = (uint32_t)P.bnx * (uint32_t)P.bny;   // brick index strides
+    const uint32_t sA = sel3(ax_a, str0, str1, str2), sB = sel3(ax_b, str0, str1, str2), sM = sel3(ax_m, str0, str1, str2);
+    // per-lane loader constants of piece q: torus coordinates (ta, tb) of the slot this lane's 16-byte chunk belongs to,
+    // the chunk's index inside the slot, and whether the slot exists
+    int ld_ta[TS_MAX_PIECES], ld_tb[TS_MAX_PIECES], ld_part[TS_MAX_PIECES];
+    bool ld_ok[TS_MAX_PIECES];
+#pragma unroll
+    for (int q = 0; q < TS_MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
+    if (stage && any_prefix) {
+        // torus position of every layer's rectangle origin (second word of the plan entries)
+        for (int L = (int)threadIdx.x; L < nbr_m; L += TS_THREADS) {
+            uint2 e = plan[L];
+            e.y |= ((e.x & 0xffffu) % (uint32_t)RA) << 16 | ((e.x >> 16) % (uint32_t)RB) << 24;
+            plan[L] = e;
+        }
+        // torus tables: N + 1 entries per axis (the last one repeats voxel N - 1: the + 1 tap of the last cell is the
+        // clamped one), ELEMENT offsets: slot of brick (i >> 2) mod R + position inside the 5x4x4 apron brick
+        const int na = P.nx + P.ny + P.nz + 3;
+        for (int e = (int)threadIdx.x; e < na; e += TS_THREADS) {
+            int axis, ii;
+            if (e < P.nx + 1) { axis = 0; ii = min(e, P.nx - 1); }
+            else if (e < P.nx + P.ny + 2) { axis = 1; ii = min(e - P.nx - 1, P.ny - 1); }
+            else { axis = 2; ii = min(e - P.nx - P.ny - 2, P.nz - 1); }
+            const int R = axis == ax_a ? RA : (axis == ax_b ? RB : RZ);
+            const uint32_t stride = axis == ax_a ? (uint32_t)APRON_BRICK_VOXELS : (axis == ax_b ? (uint32_t)RA * APRON_BRICK_VOXELS : (uint32_t)(RA * RB) * APRON_BRICK_VOXELS);
+            const uint32_t in = (uint32_t)(ii & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u));
+            tab[e] = (uint16_t)((uint32_t)((ii >> 2) % R) * stride + in);
+        }
+#pragma unroll
+        for (int q = 0; q < TS_MAX_PIECES; q++) {
+            const int c = (q * TS_NW + (int)wave) * 64 + (int)lane;
+            const int slot = c / C::CH;
+            ld_part[q] = c - slot * C::CH;
+            ld_tb[q] = slot / RA;
+            ld_ta[q] = slot - ld_tb[q] * RA;
+            ld_ok[q] = slot < RA * RB && q < pieces;
+        }
+    }
+    __syncthreads();
+    const uint32_t ring_base = lds_offset_of(ring);
+    const uint16_t *tab_x = tab, *tab_y = tab + P.nx + 1, *tab_z = tab + P.nx + P.ny + 2;
+
+    // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ; returns the number of DMA
+    // instructions this wavefront issued
+    auto issue_layer = [&](int L) -> int {
+        if (L < 0 || L >= nbr_m) return 0;
+        const uint2 e = plan[L];
+        const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+        const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
+        const int dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u), la = (int)((ey >> 16) & 255u), lb = (int)(ey >> 24);
+        const int lz = L % RZ;
+        const uint32_t layer_idx = (uint32_t)L * sM;
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < TS_MAX_PIECES; q++) {
+            if (q >= pieces) break;
+            int oa = ld_ta[q] - la, ob = ld_tb[q] - lb;
+            if (oa < 0) oa += RA;
+            if (ob < 0) ob += RB;
+            const bool ok = ld_ok[q] && oa <= dda && ob <= ddb;
+            if (__any(ok ? 1 : 0)) {
+                if (ok) {
+                    const uint32_t brick = __umul24((uint32_t)(lo_a + oa), sA) + __umul24((uint32_t)(lo_b + ob), sB) + layer_idx;
+                    const uint8_t *g = src + (uint64_t)brick * (uint64_t)C::SLOT + (uint64_t)(ld_part[q] * 16);
+                    glds16(g, ring_base + (uint32_t)lz * layer_bytes + (uint32_t)(q * TS_NW + (int)wave) * 1024u);
+                }
+                n++;
+            }
+        }
+        return n;
+    };
+
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
+    unsigned st_samples = 0, st_iters = 0;
+#endif
+    if (stage && any_prefix) {
+        // ---- prologue: the layers phases 0 .. LA-1 read
+        if (sgn > 0) { for (int l = 0; l <= LA; l++) (void)issue_layer(L0 + l); }
+        else { for (int l = 1; l >= 1 - LA; l--) (void)issue_layer(L0 + l); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const VoxelT *ringv = reinterpret_cast<const VoxelT *>(ring);
+        for (int p = 0; p < n_phases; p++) {
+            const int L = L0 + sgn * p;
+            // the layer that phase p + LA reads first
+            const int n_new = issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
+            // ---- this phase's samples: the ones whose cell lies in layer L
+            for (;;) {
+                float fx, fy, fz;
+                scaled_here(fx, fy, fz);
+                const float ux = fmaxf(fx - 0.5f, 0.0f), uy = fmaxf(fy - 0.5f, 0.0f), uz = fmaxf(fz - 0.5f, 0.0f);
+                const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;      // == floor: u >= 0
+                bool valid = rem > 0 && (sel3(ax_m, i0, j0, k0) >> 2) == L;
+                if (!__any(valid ? 1 : 0)) break;
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
+                st_iters++;
+#endif
+                if (valid && da >= 0.95f) { done = true; rem = 0; valid = false; }   // the shader's test before the sample (VolumeRenderer.cs:118)
+                if (valid) {
+                    const float ax = ux - floorf(ux), ay = uy - floorf(uy), az = uz - floorf(uz);
+                    const uint32_t x0 = tab_x[i0], y0 = tab_y[j0], y1 = tab_y[j0 + 1], z0 = tab_z[k0], z1 = tab_z[k0 + 1];
+                    const VoxelT *p00 = ringv + (x0 + y0 + z0), *p10 = ringv + (x0 + y1 + z0), *p01 = ringv + (x0 + y0 + z1), *p11 = ringv + (x0 + y1 + z1);
+                    uint32_t tv[8];
+                    tv[0] = (uint32_t)p00[0]; tv[1] = (uint32_t)p00[1]; tv[2] = (uint32_t)p10[0]; tv[3] = (uint32_t)p10[1];
+                    tv[4] = (uint32_t)p01[0]; tv[5] = (uint32_t)p01[1]; tv[6] = (uint32_t)p11[0]; tv[7] = (uint32_t)p11[1];
+                    float c, cg = 0.0f, cb = 0.0f, a;
+                    shade(tv, ax, ay, az, c, cg, cb, a);
+                    accumulate(c, cg, cb, a);
+                    advance();
+                    i++; rem--;
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
+                    st_samples++;
+#endif
+                }
+            }
+            // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
+            // that is the layer just requested, with two it was requested a phase ago
+            slab_wait_pieces(LA >= 2 ? n_new : 0);
+            // every 4th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
+            if ((p & 3) == 3) { if (__syncthreads_and(rem == 0 ? 1 : 0)) break; }
+            else __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no DMA may outlive the workgroup's LDS
+    } else if (any_prefix) {
+        // ---- not staged: the prefix on global taps, sample by sample (positions inside the safe prefix: no bounds tests)
+        while (rem > 0) {
+            if (da >= 0.95f) { done = true; break; }
+            float fx, fy, fz, ax, ay, az, c, cg = 0.0f, cb = 0.0f, a;
+            uint32_t tv[8];
+            scaled_here(fx, fy, fz);
+            taps_global(fx, fy, fz, tv, ax, ay, az);
+            shade(tv, ax, ay, az, c, cg, cb, a);
+            accumulate(c, cg, cb, a);
+            advance();
+            i++; rem--;
+        }
+    }
+
+    // ---- checked tail: the shader's loop, literally (also finishes any prefix sample the phases left behind)
+    float tsx = dsx, tsy = dsy, tsz = dsz;
+    if (POW2) {
+        qx = Qx / Sx; qy = Qy / Sy; qz = Qz / Sz;                        // exact: S is a power of two
+        tsx = dSx / Sx; tsy = dSy / Sy; tsz = dSz / Sz;
+    }
+    if (hit && !done) {
+        for (; i < P.max_steps; i++)
+            if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
+    }
+    if (!in_image) return;
+    const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
+    if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
+    else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
+    else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)      // per-tile statistics instead of the fetch count of the tile's first pixel
+    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | ((unsigned)RZ << 4) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
+#endif
+    if (spp) spp[pix] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------ dispatch
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
+static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                               uint32_t *spp, hipStream_t st)
+{
+    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE>), dim3(L.tile_table_blocks), dim3(TS_THREADS), 0, st, P,
+                       (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table);
+    return hipGetLastError();
+}
+
+template <typename VoxelT, int VIEW, int MODE>
+static hipError_t dispatch_tslab3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                  uint32_t *spp, hipStream_t st)
+{
+    const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
+    if (L.divmode_tc == DIV_CERT) return launch_tslab<VoxelT, DIV_CERT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+    if (pow2) return launch_tslab<VoxelT, DIV_UNIT, VIEW, true, MODE>(P, L, vol, tf, fb, spp, st);
+    return launch_tslab<VoxelT, DIV_UNIT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+}
+
+template <typename VoxelT>
+static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                 uint32_t *spp, hipStream_t st)
+{
+    const int view = P.view_top == 1 ? 1 : (P.view_bottom == 1 ? 2 : 0);
+    const int mode = (L.mip ? 1 : 0) + (P.tf_len > 1 ? 2 : 0);
+#define VR_TSLAB_M(VW)                                                                                         \
+    switch (mode) {                                                                                            \
+    case 0: return dispatch_tslab3<VoxelT, VW, 0>(P, L, vol, tf, fb, spp, st);                                 \
+    case 1: return dispatch_tslab3<VoxelT, VW, 1>(P, L, vol, tf, fb, spp, st);                                 \
+    case 2: return dispatch_tslab3<VoxelT, VW, 2>(P, L, vol, tf, fb, spp, st);                                 \
+    default: return dispatch_tslab3<VoxelT, VW, 3>(P, L, vol, tf, fb, spp, st);                                \
+    }
+    if (view == 0) { VR_TSLAB_M(0) }
+    if (view == 1) { VR_TSLAB_M(1) }
+    VR_TSLAB_M(2)
+#undef VR_TSLAB_M
+}
+
+// translation units: 0 = u8 volumes, 1 = u16 volumes; -1 = both
+#ifndef VR_TSLAB_TU
+#define VR_TSLAB_TU -1
+#endif
+#if VR_TSLAB_TU == 0 || VR_TSLAB_TU == -1
+hipError_t launch_raymarch_slab_tri_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                       uint32_t *spp, hipStream_t st)
+{
+    return dispatch_tslab<uint8_t>(P, L, vol, tf, fb, spp, st);
+}
+#endif
+#if VR_TSLAB_TU == 1 || VR_TSLAB_TU == -1
+hipError_t launch_raymarch_slab_tri_u16(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                        uint32_t *spp, hipStream_t st)
+{
+    return dispatch_tslab<uint16_t>(P, L, vol, tf, fb, spp, st);
+}
+#endif
+
+}  // namespace vr
