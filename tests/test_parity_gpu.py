@@ -711,15 +711,17 @@ def test_trilinear_kernel_full_size_equals_generic(vra, cfg3):
     try:
         for mip in (False, True):
             r.setMIP(mip)
-            r.setKernelVariant(0); r.render()
-            assert r.last_kernel_name == "raymarch_tri_kernel"
-            a = r.readPixels().copy()
-            na = r.countSamples()
             r.setKernelVariant(1); r.render()
             assert r.last_kernel_name == "raymarch_generic_kernel"
             b = r.readPixels().copy()
             nb = r.countSamples()
-            assert na == nb and np.array_equal(a.view(np.uint32), b.view(np.uint32)), mip
+            # automatic choice at the (axis-aligned) default pose: the LDS-staged kernel; variant 2: the batched kernel
+            for variant, name in ((0, "raymarch_slab_tri_kernel"), (2, "raymarch_tri_kernel")):
+                r.setKernelVariant(variant); r.render()
+                assert r.last_kernel_name == name
+                a = r.readPixels().copy()
+                na = r.countSamples()
+                assert na == nb and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (mip, name)
     finally:
         r.setMIP(False); r.setKernelVariant(0); r.setFilter(R.FILTER_NEAREST)
 
@@ -1032,6 +1034,7 @@ def test_trilinear_apron_copy_is_invisible(vra, oracle, dtype):
             r.setVolume(vol, spacing)
             r.setWindow(lo, hi)
             r.setFilter(R.FILTER_TRILINEAR)
+            r.setKernelVariant(2)                                # the batched trilinear kernel (variant 0 may pick the LDS-staged one)
             for mip, alpha in ((False, 0.05), (True, 0.5), (False, 1.0)):
                 r.setAlpha(alpha); r.setMIP(mip)
                 for name, block in orbit_blocks(oracle):

@@ -8,12 +8,16 @@ vra = importlib.import_module("volume-renderer_amd")
 R = vra.renderer
 r = vra.RendererCore(0)
 r.setup((1920, 1080)); r.loadShader("x"); r.setQuirks(0)
-r.generateSynthetic(R.SYNTH_NOISE_BALL, (1024, 1024, 1024), 2, 0x9E3779B9)
-r.setWindow(0, 4095); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+b = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
+r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
+r.setKernelVariant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+poses = sys.argv[2] if len(sys.argv) > 2 else "both"
 
 
 def ms(n=20):
-    for _ in range(40):
+    for _ in range(80):
         r.renderAsync()
     r.synchronize(); r.render(); r.kernelMsTake()
     for _ in range(n):
@@ -22,6 +26,7 @@ def ms(n=20):
 
 
 out = {"default": ms()}
-r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
-out["offaxis"] = ms(10)
+if poses == "both":
+    r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+    out["offaxis"] = ms(10)
 print(r.last_kernel_name, {k: round(v, 4) for k, v in out.items()})

@@ -616,7 +616,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
     L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
-    L.tri_slab = force_generic == 6 ? 1 : 0;                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible
+    L.tri_slab = force_generic == 6 ? 1 : 0;                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -855,6 +855,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     //     early (alpha >= 0.5: the speculative batch is wasted, 0.198 vs 0.189 ms): equal at the default pose
     //     (0.454 ms), 3-14 % faster over oblique poses, 12 % at an N = 4 shard (0.163 vs 0.185 ms).
     const bool aligned = viewAxisAlignment(P) >= 0.92;
+    // TRILINEAR: the LDS-staged kernel (vr_tslab.hip) when the view is aligned with a volume axis -- its tiles' brick
+    // layers then fit the ring three deep (cfg3 default pose: every tile staged, 1.36 vs 1.93 ms); an oblique view's
+    // layers are ~1.5x as large, most tiles would march on global taps (4.1 vs 3.2 ms), so it keeps the batched kernel.
+    // Volumes the batched kernel cannot take (beyond 32-bit offsets, or with a transfer function) always go staged.
+    if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L) && (aligned || !tri_path_candidate(P, L))) L.tri_slab = 1;
     L.sparse_shard = (tile_active_ < (aligned ? 256u : 1024u)) ? 1 : 0;
     if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)

@@ -44,10 +44,14 @@
 namespace vr {
 
 constexpr int TS_NW = 8, TS_THREADS = 64 * TS_NW;         // one 32x16-pixel tile per workgroup
+// LDS per workgroup: two workgroups per CU (80 KiB each).  The ring has to hold three 144-slot layers of 160 B for the
+// 1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables take 20 KiB.  Three
+// workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose layers fit (512^3: 0.711 vs
+// 0.713 ms): the loop is bound by VALU issue, not by latency.
 #if defined(VR_EXPERIMENTS) && defined(VR_X_LDSKB)
-constexpr int TS_LDS_BYTES = VR_X_LDSKB * 1024 - 512;
+template <typename VoxelT> constexpr int ts_lds_bytes() { return VR_X_LDSKB * 1024 - 512; }
 #else
-constexpr int TS_LDS_BYTES = 80 * 1024 - 512;             // two workgroups per CU (160 KiB)
+template <typename VoxelT> constexpr int ts_lds_bytes() { return 80 * 1024 - 512; }
 #endif
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
 constexpr int TS_MAX_PIECES = 3;                          // 1-KiB DMA pieces per wavefront per layer
@@ -59,12 +63,10 @@ struct TslabCfg {
     static constexpr int SLOT = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // 80 B (u8) / 160 B (u16)
     static constexpr int CH = SLOT / 16;                                          // 16-byte chunks per slot
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
-    static constexpr int TAB_AXES = sizeof(VoxelT) == 1 ? 6144 : 3072;            // nx + ny + nz
-    static constexpr int TAB_ENTRIES = TAB_AXES + 4;                              // + one duplicated last entry per axis
     static constexpr int MISC_BYTES = 512;
-    // ring + plan; torus tables are 16-bit ELEMENT offsets, so the region may reach 64 Ki elements
-    static constexpr int REGION_RAW = TS_LDS_BYTES - LUT_BYTES - TAB_ENTRIES * 2 - MISC_BYTES;
-    static constexpr int REGION = (REGION_RAW > 65535 * (int)sizeof(VoxelT) ? 65535 * (int)sizeof(VoxelT) : REGION_RAW) / 16 * 16;
+    // one region carved per tile into [ring | plan | torus tables]: the tables' size follows the volume's dimensions
+    // (2 bytes per voxel index of the two minor axes, 4 per index of the major axis)
+    static constexpr int REGION = (ts_lds_bytes<VoxelT>() - LUT_BYTES - MISC_BYTES) / 16 * 16;
     static constexpr int LAYER_SLOTS_MAX = TS_MAX_PIECES * TS_NW * 64 / CH;
 };
 
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     using C = TslabCfg<VoxelT, MODE>;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
-    __shared__ uint16_t tab[C::TAB_ENTRIES];
     __shared__ float corner[5][4];              // rows 0..3: G of the corner rays, row 4: E (voxel coordinates)
     __shared__ int red[8];                      // 0: min first progress, 1: max last progress, 2: max prefix length, 3 / 4: max rectangle extents
     static_assert(sizeof(corner) + sizeof(red) <= C::MISC_BYTES, "LDS budget");
@@ -190,14 +191,9 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     // interpolation (x, then y, then z), window and classification of one sample from its eight taps
     // tv[0..7] = (x0, x1) of the (y0,z0), (y1,z0), (y0,z1), (y1,z1) corners -- the generic kernel's operations
     const float tf_scale = (float)(P.tf_len - 1);
-    auto shade = [&](const uint32_t *tv, float ax, float ay, float az, float &c, float &cg, float &cb, float &a) {
-        const float c000 = (float)tv[0], c100 = (float)tv[1], c010 = (float)tv[2], c110 = (float)tv[3];
-        const float c001 = (float)tv[4], c101 = (float)tv[5], c011 = (float)tv[6], c111 = (float)tv[7];
-        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-        float sv = c0 + az * (c1 - c0);
-        sv = fminf(fmaxf(sv, P.fmin), P.fmax);                           // never NaN here
+    // window + classification of one interpolated sample (VolumeRenderer.cs:122-131 / :164)
+    auto classify = [&](float sv, float &c, float &cg, float &cb, float &a) {
+        sv = __builtin_amdgcn_fmed3f(sv, P.fmin, P.fmax);                // == min(max(sv, fmin), fmax): fmin <= fmax, never NaN here; one instruction
         sv = div_cert(sv - P.fmin, P.fden, P.rden);
         if (MODE >= 2) {
             int idx = (int)(sv * tf_scale + 0.5f);                       // sv in [0, 1]: truncation == floor
@@ -208,6 +204,14 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             a = sv * P.alpha_scale;
             c = sv * a;
         }
+    };
+    auto shade = [&](const uint32_t *tv, float ax, float ay, float az, float &c, float &cg, float &cb, float &a) {
+        const float c000 = (float)tv[0], c100 = (float)tv[1], c010 = (float)tv[2], c110 = (float)tv[3];
+        const float c001 = (float)tv[4], c101 = (float)tv[5], c011 = (float)tv[6], c111 = (float)tv[7];
+        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+        classify(c0 + az * (c1 - c0), c, cg, cb, a);
     };
     auto accumulate = [&](float c, float cg, float cb, float a) {
         if (MODE == 1) {
@@ -326,9 +330,17 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const float nmax = fmaxf(fmaxf(P.fdim[0], P.fdim[1]), P.fdim[2]);
     const float emax = fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fabsf(E[2]));
     const float delta = TS_MARGIN + (float)kmax * 1.2e-7f * nmax + emax * 2.4e-7f;
-    int plan_bytes = (nbr_m * 8 + 15) & ~15;
-    if (plan_bytes > C::REGION / 2) stage = false;
-    uint2 *plan = reinterpret_cast<uint2 *>(ring + (stage ? C::REGION - plan_bytes : 0));
+    // LDS carve-up behind the ring: the plan (8 bytes per layer), then the torus tables -- BYTE offsets, 16-bit for the two
+    // minor axes (a slot row / a layer is < 64 KiB), 32-bit for the major axis (ring base + layer slot + plane)
+    const int ndim_a = sel3(ax_a, P.nx, P.ny, P.nz), ndim_b = sel3(ax_b, P.nx, P.ny, P.nz);
+    const int plan_bytes = (nbr_m * 8 + 15) & ~15;
+    const int taba_bytes = ((ndim_a + 1) * 2 + 3) & ~3, tabb_bytes = ((ndim_b + 1) * 2 + 3) & ~3, tabm_bytes = (ndim_m + 1) * 4;
+    const int tail_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 15) & ~15;
+    if (tail_bytes > C::REGION / 2) stage = false;
+    uint8_t *tail = ring + (stage ? C::REGION - tail_bytes : 0);
+    uint2 *plan = reinterpret_cast<uint2 *>(tail);
+    uint16_t *tab_a = reinterpret_cast<uint16_t *>(tail + plan_bytes), *tab_b = reinterpret_cast<uint16_t *>(tail + plan_bytes + taba_bytes);
+    uint32_t *tab_m = reinterpret_cast<uint32_t *>(tail + plan_bytes + taba_bytes + tabb_bytes);
     if (stage && any_prefix) {
         for (int L = (int)threadIdx.x; L < nbr_m; L += TS_THREADS) {
             const float c_lo = (float)(4 * L) - 0.5f - delta, c_hi = (float)(4 * L) + 4.5f + delta;
@@ -359,8 +371,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     }
     __syncthreads();
     const int RA = uniform_i(red[3]) + 1, RB = uniform_i(red[4]) + 1;
-    const int slots_avail = (C::REGION - plan_bytes) / C::SLOT;
-    if (RA * RB > C::LAYER_SLOTS_MAX || RA * RB * 3 > slots_avail || RA > 255 || RB > 255) stage = false;
+    const int slots_avail = (C::REGION - tail_bytes) / C::SLOT;
+    if (RA * RB > C::LAYER_SLOTS_MAX || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * C::SLOT > 65535) stage = false;
     const int RZ = stage ? min(slots_avail / (RA * RB), 4) : 1;
     const int LA = RZ - 2;                                               // phases of prefetch distance: 1 or 2
     const uint32_t layer_bytes = (uint32_t)(RA * RB * C::SLOT);
@@ -381,17 +393,22 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             plan[L] = e;
         }
         // torus tables: N + 1 entries per axis (the last one repeats voxel N - 1: the + 1 tap of the last cell is the
-        // clamped one), ELEMENT offsets: slot of brick (i >> 2) mod R + position inside the 5x4x4 apron brick
-        const int na = P.nx + P.ny + P.nz + 3;
+        // clamped one): byte offset of the slot of brick (i >> 2) mod R + of the position inside the 5x4x4 apron brick;
+        // the major axis' entries include the ring's LDS base, so a tap address is the plain sum of three entries
+        const int na = ndim_a + ndim_b + ndim_m + 3;
         for (int e = (int)threadIdx.x; e < na; e += TS_THREADS) {
-            int axis, ii;
-            if (e < P.nx + 1) { axis = 0; ii = min(e, P.nx - 1); }
-            else if (e < P.nx + P.ny + 2) { axis = 1; ii = min(e - P.nx - 1, P.ny - 1); }
-            else { axis = 2; ii = min(e - P.nx - P.ny - 2, P.nz - 1); }
-            const int R = axis == ax_a ? RA : (axis == ax_b ? RB : RZ);
-            const uint32_t stride = axis == ax_a ? (uint32_t)APRON_BRICK_VOXELS : (axis == ax_b ? (uint32_t)RA * APRON_BRICK_VOXELS : (uint32_t)(RA * RB) * APRON_BRICK_VOXELS);
-            const uint32_t in = (uint32_t)(ii & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u));
-            tab[e] = (uint16_t)((uint32_t)((ii >> 2) % R) * stride + in);
+            int role, ii;                                                // role 0 / 1 / 2 = axis a / b / m
+            if (e < ndim_a + 1) { role = 0; ii = min(e, ndim_a - 1); }
+            else if (e < ndim_a + ndim_b + 2) { role = 1; ii = min(e - ndim_a - 1, ndim_b - 1); }
+            else { role = 2; ii = min(e - ndim_a - ndim_b - 2, ndim_m - 1); }
+            const int axis = role == 0 ? ax_a : (role == 1 ? ax_b : ax_m);
+            const int R = role == 0 ? RA : (role == 1 ? RB : RZ);
+            const uint32_t stride = role == 0 ? (uint32_t)C::SLOT : (role == 1 ? (uint32_t)(RA * C::SLOT) : (uint32_t)(RA * RB * C::SLOT));
+            const uint32_t in = (uint32_t)(ii & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u)) * (uint32_t)sizeof(VoxelT);
+            const uint32_t off = (uint32_t)((ii >> 2) % R) * stride + in;
+            if (role == 0) tab_a[e] = (uint16_t)off;
+            else if (role == 1) tab_b[e - ndim_a - 1] = (uint16_t)off;
+            else tab_m[e - ndim_a - ndim_b - 2] = off + lds_offset_of(ring);
         }
 #pragma unroll
         for (int q = 0; q < TS_MAX_PIECES; q++) {
@@ -405,7 +422,6 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     }
     __syncthreads();
     const uint32_t ring_base = lds_offset_of(ring);
-    const uint16_t *tab_x = tab, *tab_y = tab + P.nx + 1, *tab_z = tab + P.nx + P.ny + 2;
 
     // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ; returns the number of DMA
     // instructions this wavefront issued
@@ -439,55 +455,132 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
 
 #if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
     unsigned st_samples = 0, st_iters = 0;
+    const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();
 #endif
-    if (stage && any_prefix) {
+    // The staged march, compiled once per major axis M (the tables of the minor axes are 16-bit, M's 32-bit; the layer of
+    // a sample is its M index >> 2)
+    auto staged_march = [&](auto m_tag) {
+        constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0, B = M == 2 ? 1 : 2;
         // ---- prologue: the layers phases 0 .. LA-1 read
         if (sgn > 0) { for (int l = 0; l <= LA; l++) (void)issue_layer(L0 + l); }
         else { for (int l = 1; l >= 1 - LA; l--) (void)issue_layer(L0 + l); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const VoxelT *ringv = reinterpret_cast<const VoxelT *>(ring);
+        // prepared sample (the one at the current position): tap BYTE addresses of the (y0,z0), (y1,z0), (y0,z1), (y1,z1)
+        // corner pairs, the three weights, its layer along m.  prepare() runs once per sample -- right after the advance --
+        // so a ray that waits for its layer's phase keeps the values across the barrier instead of recomputing them.
+        uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
+        float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+        int lay = -0x7fffffff;
+        const uint32_t tab_a_b = lds_offset_of(tab_a), tab_b_b = lds_offset_of(tab_b), tab_m_b = lds_offset_of(tab_m);
+        // byte offset of voxel index `idx` (and of idx + 1) along voxel axis AX, from the table of the role AX plays
+        auto look = [&](auto ax_tag, int idx, uint32_t &o0, uint32_t &o1) {
+            constexpr int AX = decltype(ax_tag)::value;
+            if (AX == M) {
+                VR_LDS_AS const uint32_t *e = reinterpret_cast<VR_LDS_AS const uint32_t *>((size_t)(tab_m_b + 4u * (uint32_t)idx));
+                o0 = e[0]; if (AX != 0) o1 = e[1];
+            } else {
+                VR_LDS_AS const uint16_t *e = reinterpret_cast<VR_LDS_AS const uint16_t *>((size_t)((AX == A ? tab_a_b : tab_b_b) + 2u * (uint32_t)idx));
+                o0 = e[0]; if (AX != 0) o1 = e[1];
+            }
+        };
+        // (the weights are derived from ux, uy, uz by the caller AFTER the previous sample has used its own: no copies)
+        float ux = 0.0f, uy = 0.0f, uz = 0.0f;
+        auto prepare = [&]() {
+            float fx, fy, fz;
+            scaled_here(fx, fy, fz);
+            ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f);
+            const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor: u >= 0
+            lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> 2;
+            uint32_t x0, xunused = 0, y0, y1, z0, z1;
+            look(std::integral_constant<int, 0>{}, i0, x0, xunused);     // the x1 taps are the x0 taps' next elements (apron)
+            look(std::integral_constant<int, 1>{}, j0, y0, y1);
+            look(std::integral_constant<int, 2>{}, k0, z0, z1);
+            const uint32_t xz0 = x0 + z0, xz1 = x0 + z1;
+            a00 = xz0 + y0; a10 = xz0 + y1; a01 = xz1 + y0; a11 = xz1 + y1;
+        };
+        auto weights = [&]() { wx = __builtin_amdgcn_fractf(ux); wy = __builtin_amdgcn_fractf(uy); wz = __builtin_amdgcn_fractf(uz); };   // == u - floor(u), exact: u >= 0
+        prepare(); weights();
+        // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
+        float takenf = 0.0f;
+        const float limitf = (float)rem;
         for (int p = 0; p < n_phases; p++) {
             const int L = L0 + sgn * p;
             // the layer that phase p + LA reads first
             const int n_new = issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
-            // ---- this phase's samples: the ones whose cell lies in layer L
+            // ---- this phase's samples: the ones whose cell lies in layer L.  The body is straight-line code for the whole
+            // wavefront: a lane without a sample in this layer reads taps at its (valid, unchanged) prepared addresses and
+            // drops the result -- exec-mask branches around the body cost more scalar instructions than the arithmetic
+            // they would save (39 SALU per iteration in the branchy build).  Predication is arithmetic where that is exact:
+            // vf = 1.0 / 0.0, position += step * vf (one fma: == the shader's addition, or the position itself), the
+            // compositing weight (1 - dest.a) * vf.  A ray that has reached dest.a >= 0.95 takes no more samples (the
+            // shader's test before every sample, VolumeRenderer.cs:118; dest.a never decreases).
+            // (a second, select-free copy of the body for the iterations in which every lane has a sample -- four out of five --
+            // measured SLOWER: 1.65 vs 1.51 ms; the look-ups issued at the end of one copy are consumed by either)
             for (;;) {
-                float fx, fy, fz;
-                scaled_here(fx, fy, fz);
-                const float ux = fmaxf(fx - 0.5f, 0.0f), uy = fmaxf(fy - 0.5f, 0.0f), uz = fmaxf(fz - 0.5f, 0.0f);
-                const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;      // == floor: u >= 0
-                bool valid = rem > 0 && (sel3(ax_m, i0, j0, k0) >> 2) == L;
+                const bool valid = takenf < limitf && lay == L && da < 0.95f;
                 if (!__any(valid ? 1 : 0)) break;
 #if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
                 st_iters++;
+                st_samples += valid ? 1 : 0;
 #endif
-                if (valid && da >= 0.95f) { done = true; rem = 0; valid = false; }   // the shader's test before the sample (VolumeRenderer.cs:118)
-                if (valid) {
-                    const float ax = ux - floorf(ux), ay = uy - floorf(uy), az = uz - floorf(uz);
-                    const uint32_t x0 = tab_x[i0], y0 = tab_y[j0], y1 = tab_y[j0 + 1], z0 = tab_z[k0], z1 = tab_z[k0 + 1];
-                    const VoxelT *p00 = ringv + (x0 + y0 + z0), *p10 = ringv + (x0 + y1 + z0), *p01 = ringv + (x0 + y0 + z1), *p11 = ringv + (x0 + y1 + z1);
-                    uint32_t tv[8];
-                    tv[0] = (uint32_t)p00[0]; tv[1] = (uint32_t)p00[1]; tv[2] = (uint32_t)p10[0]; tv[3] = (uint32_t)p10[1];
-                    tv[4] = (uint32_t)p01[0]; tv[5] = (uint32_t)p01[1]; tv[6] = (uint32_t)p11[0]; tv[7] = (uint32_t)p11[1];
-                    float c, cg = 0.0f, cb = 0.0f, a;
-                    shade(tv, ax, ay, az, c, cg, cb, a);
-                    accumulate(c, cg, cb, a);
-                    advance();
-                    i++; rem--;
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-                    st_samples++;
+                const float vf = valid ? 1.0f : 0.0f;
+                VR_LDS_AS const VoxelT *p00 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a00), *p10 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a10);
+                VR_LDS_AS const VoxelT *p01 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a01), *p11 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a11);
+#if defined(VR_EXPERIMENTS) && defined(VR_X_NOTAPS)
+                const uint32_t v000 = a00 & 255u, v100 = a10 & 255u, v010 = a01 & 255u, v110 = a11 & 255u, v001 = (a00 >> 8) & 255u, v101 = (a10 >> 8) & 255u, v011 = (a01 >> 8) & 255u, v111 = (a11 >> 8) & 255u;
+                (void)p00; (void)p10; (void)p01; (void)p11;
+#else
+                const uint32_t v000 = p00[0], v100 = p00[1], v010 = p10[0], v110 = p10[1], v001 = p01[0], v101 = p01[1], v011 = p11[0], v111 = p11[1];
 #endif
+                // the next sample's position and table look-ups travel with the taps (a lane that did not advance prepares
+                // the same sample again: same values)
+                if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
+                else { qx = __builtin_fmaf(dsx, vf, qx); qy = __builtin_fmaf(dsy, vf, qy); qz = __builtin_fmaf(dsz, vf, qz); }
+                takenf += vf;
+                prepare();
+                const float ax = wx, ay = wy, az = wz;
+                const float c000 = (float)v000, c100 = (float)v100, c010 = (float)v010, c110 = (float)v110;
+                const float c001 = (float)v001, c101 = (float)v101, c011 = (float)v011, c111 = (float)v111;
+                const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+                const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+                const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+                float c, cg = 0.0f, cb = 0.0f, a;
+                classify(c0 + az * (c1 - c0), c, cg, cb, a);
+                if (MODE == 1) {
+                    da = (valid && da < a) ? a : da;
+                } else if (MODE == 3) {
+                    const bool take = valid && da < a;
+                    drgb = take ? c : drgb; dg = take ? cg : dg; db = take ? cb : db; da = take ? a : da;
+                } else {
+                    const float om = __builtin_fmaf(-da, vf, vf);       // (1 - dest.a) or 0: x + y * 0 == x, the sample of a lane that has none adds nothing
+                    drgb += c * om;
+                    if (MODE == 2) { dg += cg * om; db += cb * om; }
+                    da += a * om;
                 }
+                weights();                                               // of the sample just prepared
             }
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
-            slab_wait_pieces(LA >= 2 ? n_new : 0);
+#if !(defined(VR_EXPERIMENTS) && defined(VR_X_NOWAIT))
+            slab_wait_pieces(LA >= 2 ? uniform_i(n_new) : 0);
+#endif
             // every 4th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
-            if ((p & 3) == 3) { if (__syncthreads_and(rem == 0 ? 1 : 0)) break; }
+#if defined(VR_EXPERIMENTS) && defined(VR_X_NOBAR)
+            if ((p & 31) == 31) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
+#else
+            if ((p & 3) == 3) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
             else __syncthreads();
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no DMA may outlive the workgroup's LDS
+        i += (int)takenf;
+        rem -= (int)takenf;
+    };
+    if (stage && any_prefix) {
+        if (ax_m == 0) staged_march(std::integral_constant<int, 0>{});
+        else if (ax_m == 1) staged_march(std::integral_constant<int, 1>{});
+        else staged_march(std::integral_constant<int, 2>{});
     } else if (any_prefix) {
         // ---- not staged: the prefix on global taps, sample by sample (positions inside the safe prefix: no bounds tests)
         while (rem > 0) {
@@ -520,6 +613,11 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
 #if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)      // per-tile statistics instead of the fetch count of the tile's first pixel
     if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | ((unsigned)RZ << 4) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
+    // shader-clock ticks and 100 MHz wall ticks of the staged loop (threads 1, 2), iterations and samples of wavefront 0 (threads 3, 4)
+    if (spp && threadIdx.x == 1) { spp[pix] = (uint32_t)(clock64() - st_clk0); return; }
+    if (spp && threadIdx.x == 2) { spp[pix] = (uint32_t)(wall_clock64() - st_wall0); return; }
+    if (spp && threadIdx.x == 3) { spp[pix] = st_iters; return; }
+    if (spp && threadIdx.x == 4) { spp[pix] = st_samples; return; }
 #endif
     if (spp) spp[pix] = (uint32_t)i;
 }
