@@ -41,6 +41,19 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
         if (OP == 18) asm volatile(R16(OPS8_3("v_and_or_b32")) ::: CLOB);
         if (OP == 19) asm volatile(R16(OPS8_1("v_mov_b32")) ::: CLOB);
         if (OP == 20) asm volatile(R16(OPS8_3("v_perm_b32")) ::: CLOB);
+        if (OP == 22) asm volatile(R16(OPS8("v_max_i32")) ::: CLOB);
+        if (OP == 23) asm volatile(R16(OPS8("v_min_u32")) ::: CLOB);
+        if (OP == 24) asm volatile(R16(OPS8("v_and_b32")) ::: CLOB);
+        if (OP == 25) asm volatile(R16(OPS8("v_lshlrev_b32")) ::: CLOB);
+        if (OP == 26) asm volatile(R16(OPS8_3("v_bfe_u32")) ::: CLOB);
+        if (OP == 27) asm volatile(R16(OPS8("v_mul_u32_u24")) ::: CLOB);
+        if (OP == 28) asm volatile(R16(OPS8_3("v_med3_f32")) ::: CLOB);
+        if (OP == 29) asm volatile(R16(OPS8("v_mul_f32")) ::: CLOB);
+        if (OP == 30) asm volatile(R16(OPS8_3("v_add3_u32")) ::: CLOB);
+        if (OP == 31) asm volatile(R16(OPS8("v_sub_f32")) ::: CLOB);
+        if (OP == 32) asm volatile(R16("v_add_f32 v10, 1.0, v2\n v_add_f32 v11, 0.5, v3\n v_add_f32 v12, -0.5, v2\n v_add_f32 v13, 2.0, v3\n v_add_f32 v14, 1.0, v2\n v_add_f32 v15, 0.5, v3\n v_add_f32 v16, -0.5, v2\n v_add_f32 v17, 2.0, v3\n") ::: CLOB);
+        if (OP == 33) asm volatile(R16("v_add_f32 v10, s10, v2\n v_add_f32 v11, s11, v3\n v_add_f32 v12, s10, v2\n v_add_f32 v13, s11, v3\n v_add_f32 v14, s10, v2\n v_add_f32 v15, s11, v3\n v_add_f32 v16, s10, v2\n v_add_f32 v17, s11, v3\n") ::: CLOB);
+        if (OP == 34) asm volatile(R16("v_fma_f32 v10, v2, s10, v3\n v_fma_f32 v11, v2, s11, v3\n v_fma_f32 v12, v2, s10, v3\n v_fma_f32 v13, v2, s11, v3\n v_fma_f32 v14, v2, s10, v3\n v_fma_f32 v15, v2, s11, v3\n v_fma_f32 v16, v2, s10, v3\n v_fma_f32 v17, v2, s11, v3\n") ::: CLOB);
         if (OP == 21) asm volatile(R16("s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n"
                                        "s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n") ::: CLOB);
     }
@@ -71,5 +84,7 @@ int main()
     run<16>("v_cvt_f32_ubyte0"); run<15>("v_ldexp_f32"); run<5>("v_add_lshl_u32"); run<6>("v_lshl_add_u32"); run<7>("v_add_u32"); run<13>("v_ashrrev_i32"); run<17>("v_mad_u32_u24");
     run<18>("v_and_or_b32"); run<20>("v_perm_b32"); run<19>("v_mov_b32"); run<8>("v_cndmask_b32 (vcc)"); run<9>("v_cndmask_b32_e64 (sgpr pair)"); run<10>("v_cmp_lt_f32 -> vcc"); run<11>("v_cmp_eq_u32_e64 -> sgpr");
     run<21>("s_and_b64 / s_or_b64");
+    run<22>("v_max_i32"); run<23>("v_min_u32"); run<24>("v_and_b32"); run<25>("v_lshlrev_b32"); run<26>("v_bfe_u32"); run<27>("v_mul_u32_u24"); run<28>("v_med3_f32"); run<29>("v_mul_f32"); run<30>("v_add3_u32"); run<31>("v_sub_f32");
+    run<32>("v_add_f32 (inline constant src0)"); run<33>("v_add_f32 (sgpr src0)"); run<34>("v_fma_f32 (sgpr src1)");
     return 0;
 }

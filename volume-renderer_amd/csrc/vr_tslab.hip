@@ -138,7 +138,12 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
     float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
     const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
-    const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+    // Wave-uniform constants of the sample loop are kept in VECTOR registers on purpose: on gfx950 a fp32 add / mul / fma
+    // with an SGPR operand issues at the slow rate (4.2 cycles per wavefront instruction instead of 2.3,
+    // tools/ubench/valu_rates2.hip), and the loop is bound by VALU issue.
+    auto in_vgpr = [](float v) { asm volatile("" : "+v"(v)); return v; };
+    const float Hx = in_vgpr(P.half[0] * Sx), Hy = in_vgpr(P.half[1] * Sy), Hz = in_vgpr(P.half[2] * Sz), Szv = in_vgpr(Sz), Syv = in_vgpr(Sy);
+    const float k_fmin = in_vgpr(P.fmin), k_fmax = in_vgpr(P.fmax), k_fden = in_vgpr(P.fden), k_rden = in_vgpr(P.rden), k_alpha = in_vgpr(P.alpha_scale);
 
     // voxel coordinates (floats, per voxel axis i/j/k) of a box position: an affine map, exact for POW2 and within a
     // few ulp otherwise -- only the load plan uses it, behind its margins
@@ -153,10 +158,10 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     // scaled texcoord (texcoord * dimension per voxel axis) of the CURRENT position, the shader's operations
     auto scaled_here = [&](float &fx, float &fy, float &fz) {
         if (POW2) {
-            const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+            const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
             fx = ux; fy = uy; fz = uz;
-            if (VIEW == 1) { fy = Sz - uz; fz = uy; }
-            else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+            if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+            else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
         } else {
             const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
@@ -193,15 +198,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const float tf_scale = (float)(P.tf_len - 1);
     // window + classification of one interpolated sample (VolumeRenderer.cs:122-131 / :164)
     auto classify = [&](float sv, float &c, float &cg, float &cb, float &a) {
-        sv = __builtin_amdgcn_fmed3f(sv, P.fmin, P.fmax);                // == min(max(sv, fmin), fmax): fmin <= fmax, never NaN here; one instruction
-        sv = div_cert(sv - P.fmin, P.fden, P.rden);
+        sv = __builtin_amdgcn_fmed3f(sv, k_fmin, k_fmax);                // == min(max(sv, fmin), fmax): fmin <= fmax, never NaN here; one instruction
+        sv = div_cert(sv - k_fmin, k_fden, k_rden);
         if (MODE >= 2) {
             int idx = (int)(sv * tf_scale + 0.5f);                       // sv in [0, 1]: truncation == floor
             idx = med3_i32(idx, 0, P.tf_len - 1);
             const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
             c = q.x; cg = q.y; cb = q.z; a = q.w;
         } else {
-            a = sv * P.alpha_scale;
+            a = sv * k_alpha;
             c = sv * a;
         }
     };
