@@ -159,6 +159,12 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible.
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
+/* 1 (default): under kernel variant 0 the launch is a MEASURED choice -- every candidate kernel of a configuration
+   renders identical bits, so the first frames after a change of configuration (image, shard, volume, window, opacity,
+   pose bucket) try the candidates in turn, the heuristic's choice first, three times each (HIP events on the launch
+   stream, read without blocking), and the fastest is kept.  0: the heuristic's choice only (what a single frame gets
+   anyway).  Replaces round 2's tile-count thresholds; no reference equivalent (the reference has one shader). */
+int vr_set_autotune(vr_handle h, int enable);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %
    fewer cache lines per frame; frames are bit-identical); 0: never.  Build-defined. */

@@ -968,7 +968,9 @@ def test_relay_kernel_full_size_shard(vra, cfg3):
     assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_slab_kernel")
     fast = r.readPixels()
     r.setKernelVariant(0)
-    r.render(); r.kernelMsTake()
+    for _ in range(12):                                       # the measured work model tries its candidates, then settles
+        r.render()
+    r.kernelMsTake()
     for _ in range(5):
         r.render()
     t_relay = r.kernelMsTake() / 5
@@ -1162,3 +1164,35 @@ def test_step_budget_of_10000_samples(vra, oracle, variant):
                 assert int(want_spp.max()) <= 10000
                 assert_same(got, want, spp, want_spp, what=f"10000-step cap variant {variant} alpha {alpha} pose ({ze}, {az}) kernel {r.last_kernel_name}")
         assert alpha == 1.0 or capped >= 200, capped
+
+
+@pytest.mark.parametrize("filt", ["nearest", "trilinear"])
+def test_measured_work_model_keeps_the_bits_and_settles(vra, oracle, filt):
+    """kernel variant 0 with the measured work model (vr_set_autotune, default on): the first frames of a configuration try the
+    candidate kernels in turn -- every frame must still be the oracle's frame bit for bit, more than one kernel must have
+    run, and after the exploration the choice must stay put; with the model off the heuristic's kernel runs every time"""
+    rng = np.random.default_rng(21)
+    R = vra.renderer
+    vol = rand_volume(rng, (96, 80, 72), np.uint16, smooth=True)
+    W, H = 200, 144
+    with make_renderer(vra, (W, H)) as r:
+        r.setQuirks(0); r.setVolume(vol); r.setWindow(0, 4095); r.setAlpha(0.03)
+        r.setFilter(R.FILTER_TRILINEAR if filt == "trilinear" else R.FILTER_NEAREST)
+        block = r.getCameraBlock()
+        p = oracle.OracleParams(W, H, cam=block, alpha_scale=0.03, min_val=0, max_val=4095, filter=int(filt == "trilinear"))
+        want, _ = oracle.render(vol, p)
+        seen, tail = [], []
+        for k in range(24):
+            if k % 2:
+                r.render()
+            else:
+                r.renderAsync(); r.synchronize()
+            seen.append(r.last_kernel_name)
+            assert_same(r.readPixels(), want, what=f"{filt} frame {k} via {r.last_kernel_name}")
+        assert len(set(seen[:14])) >= 2, seen                 # the exploration really ran different kernels
+        assert len(set(seen[-6:])) == 1, seen                 # ... and has settled
+        r.setAutotune(False)
+        for k in range(6):
+            r.render()
+            tail.append(r.last_kernel_name)
+        assert len(set(tail)) == 1, tail

@@ -33,6 +33,7 @@ RendererCore::RendererCore(int device) : main_cam(30), histogram(256, 0.0f), dev
         check(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking), "hipStreamCreate");
         check(hipEventCreate(&ev0_), "hipEventCreate");
         check(hipEventCreate(&ev1_), "hipEventCreate");
+        for (TuneSlot &s : tune_slot_) { check(hipEventCreate(&s.ev0), "hipEventCreate"); check(hipEventCreate(&s.ev1), "hipEventCreate"); }
         check(hipMalloc(&d_scratch_, sizeof(unsigned) * 264), "hipMalloc(scratch)");
     }
 }
@@ -51,6 +52,7 @@ RendererCore::~RendererCore()
         if (d_rgba8_) (void)hipFree(d_rgba8_);
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
+        for (TuneSlot &s : tune_slot_) { if (s.ev0) (void)hipEventDestroy(s.ev0); if (s.ev1) (void)hipEventDestroy(s.ev1); }
         if (own_stream_) (void)hipStreamDestroy(own_stream_);
     }
 }
@@ -675,6 +677,7 @@ float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
     refreshApron(P, L);
     // the specialised kernels gather from the packed copy when their address tables fit (vr_kernels.hip: dispatch_fast3)
     last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
+    tuneChoose(P, L);
     return fb;
 }
 
@@ -683,7 +686,105 @@ void RendererCore::launch(uint32_t *spp)
     FrameParams P;
     LaunchConfig L;
     float4 *fb = prepareLaunch(P, L);
+    // a measurement launch of the work model: events around the kernel, read later without blocking (tuneCollect)
+    const bool measure = tune_measure_ && spp == nullptr && tune_count_ < kTuneSlots;
+    TuneSlot &slot = tune_slot_[(tune_head_ + tune_count_) % kTuneSlots];
+    if (measure) check(hipEventRecord(slot.ev0, stream()), "hipEventRecord");
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
+    if (measure) {
+        check(hipEventRecord(slot.ev1, stream()), "hipEventRecord");
+        slot.key = tune_key_; slot.cand = tune_cand_;
+        tune_count_++;
+    }
+    tune_measure_ = false;
+}
+
+// ---- the measured work model.  Which kernel is fastest for a launch depends on how many tiles have work, how long
+// their rays are, how early they end and how oblique the view is (tools/config_sweep.py: the relay kernel wins a
+// 1024^3 shard with 171 active tiles by 25 %, loses a 256^3 frame with 560 by 45 %).  Round 2 chose by tile-count
+// thresholds fitted on one configuration; here the launch is MEASURED: all candidates render identical bits, so the
+// first frames of a configuration try them in turn (the heuristic's choice first), a few times each, and the fastest
+// is kept.  Keyed by everything that shapes the launch; the pose enters through the view's axis alignment and the
+// number of active tiles (buckets), so an orbiting camera re-uses what it has learnt.
+void RendererCore::tuneRecord(uint64_t key, int cand, float ms)
+{
+    auto it = tune_.find(key);
+    if (it == tune_.end() || cand < 0 || cand >= it->second.ncand) return;
+    TuneEntry &e = it->second;
+    e.best_ms[cand] = e.tries[cand] == 0 ? ms : std::min(e.best_ms[cand], ms);
+    e.tries[cand]++;
+    constexpr int kTries = 2;
+    bool all = true;
+    for (int c = 0; c < e.ncand; c++) all = all && e.tries[c] >= kTries;
+    if (all) {
+        int best = 0;
+        for (int c = 1; c < e.ncand; c++)
+            if (e.best_ms[c] < e.best_ms[best] * 0.99f) best = c;        // ties go to the heuristic's choice
+        e.settled = best;
+    }
+}
+
+void RendererCore::tuneCollect()
+{
+    while (tune_count_ > 0) {                                            // the stream completes them in order
+        TuneSlot &s = tune_slot_[tune_head_];
+        const hipError_t q = hipEventQuery(s.ev1);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return; }
+        tune_head_ = (tune_head_ + 1) % kTuneSlots;
+        tune_count_--;
+        if (q != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) tuneRecord(s.key, s.cand, ms);
+        else (void)hipGetLastError();
+    }
+}
+
+void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
+{
+    tune_measure_ = false;
+    tuneCollect();
+    if (!autotune || force_generic != 0 || !L.tile_table) return;
+    // candidates, the heuristic's choice (what buildFrame / refreshTileSchedule left in L) first
+    const int prior = (L.sparse_shard ? 1 : 0) | (L.pipelined ? 2 : 0) | (L.short_batches ? 4 : 0) | (L.tri_slab ? 8 : 0);
+    int cand[4], n = 0;
+    auto add = [&](int c) { for (int k = 0; k < n; k++) if (cand[k] == c) return; if (n < 4) cand[n++] = c; };
+    if (fast_path_eligible(P, L)) {
+        const bool relay_ok = !L.big_offsets && !(P.skip_empty != 0 && L.skip_grid != nullptr);
+        add(prior & (relay_ok ? 7 : 6));
+        add(P.alpha_scale >= 0.5f ? 4 : 2);                              // fast kernel: four-sample batches / pipelined loop
+        add(0);                                                          // fast kernel, plain loop
+        if (relay_ok) add(1);
+    } else if (L.filter == 1 && L.apron != nullptr && tri_slab_candidate(P, L) && tri_path_candidate(P, L)) {
+        add(prior & 8); add(8); add(0);                                  // LDS-staged / batched trilinear kernel
+    }
+    if (n < 2) return;
+    uint64_t key = tileScheduleKey(P, launch_local_rows(P), false);
+    auto mix = [&](uint64_t v) { key ^= v + 0x9E3779B97F4A7C15ull + (key << 6) + (key >> 2); };
+    mix((uint64_t)(viewAxisAlignment(P) * 25.0));
+    mix((uint64_t)(std::log2((double)std::max(tile_active_, 1u)) * 3.0));
+    uint32_t abits; std::memcpy(&abits, &P.alpha_scale, 4);
+    mix(abits); mix((uint64_t)(uint32_t)P.min_val << 32 | (uint32_t)P.max_val);
+    mix((uint64_t)P.nx << 40 | (uint64_t)P.ny << 20 | (uint64_t)P.nz);
+    mix((uint64_t)L.filter | (uint64_t)L.mip << 1 | (uint64_t)(P.tf_len > 1) << 2 | (uint64_t)(P.skip_empty != 0) << 3 | (uint64_t)L.layout << 4 |
+        (uint64_t)L.bytes_per_voxel << 5 | (uint64_t)(L.packed12 != nullptr) << 8 | (uint64_t)(L.apron != nullptr) << 9 | (uint64_t)P.fb_format << 10 |
+        (uint64_t)P.view_top << 11 | (uint64_t)P.view_bottom << 12 | (uint64_t)prior << 16);
+    if (tune_.size() > 512) tune_.clear();
+    TuneEntry &e = tune_[key];
+    if (e.ncand == 0) { e.ncand = n; for (int k = 0; k < n; k++) e.cand[k] = cand[k]; }
+    int use;
+    if (e.settled >= 0) {
+        use = e.settled;
+    } else if (tune_count_ >= kTuneSlots) {                              // every event pair is in flight: best so far
+        use = 0;
+        for (int c = 1; c < e.ncand; c++)
+            if (e.tries[c] > 0 && (e.tries[use] == 0 || e.best_ms[c] < e.best_ms[use])) use = c;
+    } else {
+        use = e.next;
+        e.next = (e.next + 1) % e.ncand;
+        tune_measure_ = true; tune_key_ = key; tune_cand_ = use;
+    }
+    const int c = e.cand[use];
+    L.sparse_shard = (c & 1) ? 1 : 0; L.pipelined = (c & 2) ? 1 : 0; L.short_batches = (c & 4) ? 1 : 0; L.tri_slab = (c & 8) ? 1 : 0;
 }
 
 // 12-bit packed copy (vr_set_pack12, default on): when every voxel of a bricked u16 volume is
@@ -831,7 +932,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f)) {
         std::vector<uint32_t> table;
-        tile_active_ = buildTileSchedule(P, rows, table);
+        tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
         if (table.size() > tile_table_capacity_) {
             if (d_tile_table_) { check(hipFree(d_tile_table_), "hipFree(tile table)"); d_tile_table_ = nullptr; }
             check(hipMalloc(reinterpret_cast<void **>(&d_tile_table_), table.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
@@ -860,7 +961,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // layers are ~1.5x as large, most tiles would march on global taps (4.1 vs 3.2 ms), so it keeps the batched kernel.
     // Volumes the batched kernel cannot take (beyond 32-bit offsets, or with a transfer function) always go staged.
     if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L) && (aligned || !tri_path_candidate(P, L))) L.tri_slab = 1;
-    L.sparse_shard = (tile_active_ < (aligned ? 256u : 1024u)) ? 1 : 0;
+    // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is
+    // a single under-filled round of long serial rays -- few active tiles, scaled by how long the rays are (1045 samples
+    // on the configuration the 256 / 1024 were measured on; a 256^3 volume's 262-sample rays want 4x fewer tiles)
+    const double len_scale = std::min(1.0, std::max(0.15, tile_longest_ / 1000.0));
+    L.sparse_shard = ((double)tile_active_ < (aligned ? 256.0 : 1024.0) * len_scale) ? 1 : 0;
     if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
     L.pipelined = (force_generic == 0 && P.alpha_scale < 0.5f) ? 1 : 0;
@@ -877,6 +982,10 @@ void RendererCore::render()
     FrameParams P;
     LaunchConfig L;
     float4 *fb = prepareLaunch(P, L);
+    const bool measure = tune_measure_;
+    const uint64_t mkey = tune_key_;
+    const int mcand = tune_cand_;
+    tune_measure_ = false;
     check(hipEventRecord(ev0_, stream()), "hipEventRecord");
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, nullptr, stream(), &last_kernel_), "raymarch launch");
     check(hipEventRecord(ev1_, stream()), "hipEventRecord");
@@ -884,6 +993,7 @@ void RendererCore::render()
     float ms = 0.0f;
     check(hipEventElapsedTime(&ms, ev0_, ev1_), "hipEventElapsedTime");
     kerneltime_sum += ms;
+    if (measure) tuneRecord(mkey, mcand, ms);                            // the blocking path measures anyway
 }
 
 void RendererCore::renderAsync()

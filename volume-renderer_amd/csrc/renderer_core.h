@@ -104,6 +104,7 @@ public:
     int pack12 = 1;                          // 1: keep a 12-bit packed copy for the fast kernel when the data allow (vr_set_pack12)
     int tri_apron = 1;                       // 1: keep an apron copy (5x4x4-stored bricks) for the TRILINEAR kernel (vr_set_trilinear_copy)
     int tile_order = 1;      // 1: longest-first tile schedule, 0: arithmetic order
+    int autotune = 1;        // 1: kernel variant 0 measures its candidate kernels on the first frames of a configuration and keeps the fastest (vr_set_autotune)
     std::string last_error;
 
 private:
@@ -159,8 +160,28 @@ private:
     uint64_t tile_table_key_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
     unsigned tile_active_ = 0;               // tiles with work in the cached schedule
+    double tile_longest_ = 0.0;              // expected samples of its longest ray
     void refreshTileSchedule(const FrameParams &P, LaunchConfig &L);
     const char *last_kernel_ = "";
+    // ---- measured work model (kernel variant 0): every candidate kernel of a configuration renders the same bits, so
+    // the first frames of a configuration double as measurements -- each candidate is timed a few times (HIP events on
+    // the launch stream, polled without blocking), the fastest is kept until the configuration changes.
+    // A candidate = bit set: 1 relay kernel, 2 pipelined batch loop, 4 four-sample batches, 8 LDS-staged trilinear kernel.
+    struct TuneEntry {
+        int ncand = 0, cand[4] = {0, 0, 0, 0}, tries[4] = {0, 0, 0, 0}, settled = -1, next = 0;
+        float best_ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    std::map<uint64_t, TuneEntry> tune_;
+    static constexpr int kTuneSlots = 12;    // asynchronous measurements that may be in flight (a burst of renderAsync calls)
+    struct TuneSlot { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t key = 0; int cand = -1; };
+    TuneSlot tune_slot_[kTuneSlots];
+    int tune_head_ = 0, tune_count_ = 0;     // ring of in-flight slots: oldest at tune_head_
+    bool tune_measure_ = false;              // the launch being prepared is a measurement of candidate tune_cand_ of entry tune_key_
+    uint64_t tune_key_ = 0;
+    int tune_cand_ = -1;
+    void tuneChoose(const FrameParams &P, LaunchConfig &L);
+    void tuneRecord(uint64_t key, int cand, float ms);
+    void tuneCollect();
 
     hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }
     void requireDevice(const char *what) const;

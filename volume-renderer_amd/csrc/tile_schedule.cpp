@@ -79,9 +79,10 @@ uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
     return hsh;
 }
 
-unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples)
 {
     unsigned active_tiles = 0;
+    double longest = 0.0;
     const unsigned tiles_x = (unsigned)((P.img_w + (int)kFastTileW - 1) / (int)kFastTileW);
     const unsigned tiles_y = (unsigned)((rows + (int)kFastTileH - 1) / (int)kFastTileH);
     // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
@@ -109,6 +110,7 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
                 }
             tile_work[(size_t)ty * tiles_x + tx] = wmax;
             if (wmax > 0.0) active_tiles++;
+            longest = std::max(longest, wmax);
         }
     }
     for (unsigned cy = 0; cy < cpc; cy++)
@@ -135,6 +137,7 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
             table[b] = tx | (ty << 16);
         }
     }
+    if (max_ray_samples) *max_ray_samples = longest;
     return active_tiles;
 }
 

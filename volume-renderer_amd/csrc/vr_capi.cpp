@@ -320,6 +320,13 @@ int vr_set_skip_empty(vr_handle h, int enable)
     return guarded(h, [&](vr::RendererCore &c) { c.skip_empty = enable != 0; });
 }
 
+int vr_set_autotune(vr_handle h, int enable)
+{
+    if (!h) return VR_E_INVALID;
+    h->core.autotune = enable ? 1 : 0;
+    return VR_OK;
+}
+
 int vr_set_kernel_variant(vr_handle h, int variant)
 {
     return guarded(h, [&](vr::RendererCore &c) {

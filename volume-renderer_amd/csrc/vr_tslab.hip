@@ -465,7 +465,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     // The staged march, compiled once per major axis M (the tables of the minor axes are 16-bit, M's 32-bit; the layer of
     // a sample is its M index >> 2)
     auto staged_march = [&](auto m_tag) {
-        constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0, B = M == 2 ? 1 : 2;
+        constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0;          // minor axes: A and the other one
         // ---- prologue: the layers phases 0 .. LA-1 read
         if (sgn > 0) { for (int l = 0; l <= LA; l++) (void)issue_layer(L0 + l); }
         else { for (int l = 1; l >= 1 - LA; l--) (void)issue_layer(L0 + l); }

@@ -117,6 +117,7 @@ def load_library() -> C.CDLL:
         "vr_set_layout": (i32, [h, i32]),
         "vr_set_skip_empty": (i32, [h, i32]),
         "vr_set_kernel_variant": (i32, [h, i32]),
+        "vr_set_autotune": (i32, [h, i32]),
         "vr_set_pack12": (i32, [h, i32]),
         "vr_get_pack12_bytes": (i32, [h, C.POINTER(C.c_size_t)]),
         "vr_set_trilinear_copy": (i32, [h, i32]),
@@ -482,6 +483,10 @@ class RendererCore:
 
     def setKernelVariant(self, variant):
         self._check(self._lib.vr_set_kernel_variant(self._h, variant))
+
+    def setAutotune(self, on):
+        """kernel variant 0: measure the candidate kernels on the first frames of a configuration and keep the fastest (default on)"""
+        self._check(self._lib.vr_set_autotune(self._h, 1 if on else 0))
 
     def setPack12(self, on):
         self._check(self._lib.vr_set_pack12(self._h, int(bool(on))))
