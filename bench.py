@@ -700,6 +700,13 @@ def extras(args, r, local, stream, b, W, H):
             r.renderAsync()
             r.readPixelsRGBA8()
         out["frame_plus_rgba8_readback_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 4)
+        # the shim's presentation path: vr_render + vr_present_rgba8 (two pinned host frames, the copy of frame i under kernel i + 1)
+        r.render(); r.presentRGBA8(copy=False)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r.render()
+            r.presentRGBA8(copy=False)
+        out["frame_plus_present_rgba8_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
         r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
     if b == 2 and not args.no_pack12 and r.pack12Bytes():
         r.setPack12(False)

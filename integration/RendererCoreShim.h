@@ -70,19 +70,32 @@ class RendererCore
             const int rc = group ? vr_group_render(group) : vr_render(handles[0]);
             if (rc != VR_OK) { title = "Error!"; msg = group ? vr_group_last_error(group) : vr_last_error(handles[0]); return; }
             kerneltime_sum += group ? vr_group_kernel_ms_take(group) : vr_kernel_ms_take(handles[0]);   // RendererGUI.cpp:58,60 reads / zeroes it
-            frame.resize((size_t)framebuffer_size.x * (size_t)framebuffer_size.y * 4);
-            if (group) vr_group_read_pixels(group, frame.data(), frame.size());
-            else vr_read_pixels(handles[0], frame.data(), frame.size());                  // D2H of the RGBA32F target
+            // presentation: RGBA8 (the precision of the back buffer the reference blits to) through two pinned host frames;
+            // the copy of this frame runs under the next frame's kernel, the frame shown is the previous one
+            frame_valid = false;
+            presented = nullptr;
+            if ((group ? vr_group_present_rgba8(group, &presented) : vr_present_rgba8(handles[0], &presented)) != VR_OK) presented = nullptr;
 #ifndef VR_SHIM_NO_GL
             glBindTexture(GL_TEXTURE_2D, blit_tex);                                       // :158-162: blit to the back buffer
-            glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, framebuffer_size.x, framebuffer_size.y, 0, GL_RGBA, GL_FLOAT, frame.data());
+            if (presented) glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA8, framebuffer_size.x, framebuffer_size.y, 0, GL_RGBA, GL_UNSIGNED_BYTE, presented);
             glBindFramebuffer(GL_READ_FRAMEBUFFER, blit_fbo);
             glFramebufferTexture2D(GL_READ_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, blit_tex, 0);
             glBindFramebuffer(GL_DRAW_FRAMEBUFFER, 0);
             glBlitFramebuffer(0, 0, framebuffer_size.x, framebuffer_size.y, 0, 0, window_size.x, window_size.y, GL_COLOR_BUFFER_BIT, GL_LINEAR);
 #endif
         }
-        const std::vector<float> &lastFrame() const { return frame; }                     // RGBA32F, row 0 = bottom (GL)
+        // the frame just rendered as RGBA32F, row 0 = bottom (GL): read back on demand (screenshots of a group, tests)
+        const std::vector<float> &lastFrame()
+        {
+            if (!frame_valid) {
+                frame.resize((size_t)framebuffer_size.x * (size_t)framebuffer_size.y * 4);
+                if (group) vr_group_read_pixels(group, frame.data(), frame.size());
+                else vr_read_pixels(handles[0], frame.data(), frame.size());
+                frame_valid = true;
+            }
+            return frame;
+        }
+        const unsigned char *presentedFrame() const { return presented; }                 // RGBA8 of the PREVIOUS render() (one frame of display latency)
 
     private:
         friend class RendererGUI;
@@ -118,6 +131,7 @@ class RendererCore
         {
             if (!group) return vr_save_image(handles[0], fn.c_str(), ext.c_str()) == VR_OK;
             std::vector<unsigned char> rgb((size_t)framebuffer_size.x * framebuffer_size.y * 3);
+            (void)lastFrame();
             for (int y = 0; y < framebuffer_size.y; y++)                                   // top row first (stbi_flip_vertically_on_write, :172)
                 for (int x = 0; x < framebuffer_size.x; x++)
                     for (int c = 0; c < 3; c++) {
@@ -165,6 +179,8 @@ class RendererCore
         std::vector<vr_handle> handles;                         // one per device (VR_DEVICES), or a single handle
         vr_group_handle group = nullptr;
         std::vector<float> frame;
+        bool frame_valid = false;
+        const unsigned char *presented = nullptr;
         unsigned blit_tex = 0, blit_fbo = 0;
 };
 

@@ -292,3 +292,36 @@ def test_assemble_shards_matches_the_index_path(vra, oracle, mode, world, channe
             r.assembleShards(gathered.data_ptr(), frame.data_ptr(), 1, 10, 0, channels, 0)
         r.setFramebufferExternal(0); r.setFramebufferCompact(False); r.setFramebufferFormat(R.FB_RGBA32F)
         r.setRowRange(0, -1); r.setRowStripes(1, 0, 1)
+
+
+def test_present_rgba8_is_double_buffered_and_one_frame_late(vra):
+    """vr_present_rgba8 (the shim's presentation path): call k returns the frame of call k - 1 (the first call its own), equal to
+    vr_read_pixels_rgba8 of that frame byte for byte; the group's variant does the same for the assembled frame"""
+    rng = np.random.default_rng(8)
+    vol = rng.integers(0, 256, size=(40, 48, 56), dtype=np.uint8)
+    size = (203, 157)
+    poses = [(0.3, 0.66), (0.12, -0.42), (-0.54, 0.18), (0.0, 0.0), (0.06, 0.06)]
+
+    def configure(r):
+        assert r.loadShader("VolumeRenderer.cs")
+        r.setQuirks(0); r.setVolume(vol); r.setWindow(5, 240); r.setAlpha(0.05)
+
+    with vra.RendererCore(0) as r:
+        r.setup(size); configure(r)
+        want = []
+        for k, (ze, az) in enumerate(poses):
+            r.resetCamera(); r.cameraOrient(0, ze, az)
+            r.render()
+            want.append(r.readPixelsRGBA8())
+            got = r.presentRGBA8()
+            assert np.array_equal(got, want[max(k - 1, 0)]), k
+        assert not np.array_equal(want[0], want[2])
+        r.setup((96, 64)); r.render()                      # a new size re-allocates the presentation buffers
+        assert np.array_equal(r.presentRGBA8(), r.readPixelsRGBA8())
+    with vra.RendererGroup([0, 0, 0]) as g:
+        g.setup(size, stripe_rows=8)
+        g.each(configure)
+        for k, (ze, az) in enumerate(poses):
+            g.each(lambda m: (m.resetCamera(), m.cameraOrient(0, ze, az)))
+            g.render()
+            assert np.array_equal(g.presentRGBA8(), want[max(k - 1, 0)]), ("group", k)

@@ -50,6 +50,7 @@ RendererCore::~RendererCore()
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
+        releasePresent();
         if (ev0_) (void)hipEventDestroy(ev0_);
         if (ev1_) (void)hipEventDestroy(ev1_);
         for (TuneSlot &s : tune_slot_) { if (s.ev0) (void)hipEventDestroy(s.ev0); if (s.ev1) (void)hipEventDestroy(s.ev1); }
@@ -1058,6 +1059,56 @@ void RendererCore::readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes)
     check(launch_to_rgba8(src, d_rgba8_, n, stream()), "to_rgba8_kernel");
     check(hipMemcpyAsync(rgba8, d_rgba8_, n * 4, hipMemcpyDeviceToHost, stream()), "hipMemcpy(D2H rgba8)");
     check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+}
+
+void RendererCore::releasePresent()
+{
+    if (present_stream_) (void)hipStreamSynchronize(present_stream_);
+    for (int s = 0; s < 2; s++) {
+        if (d_present_[s]) { (void)hipFree(d_present_[s]); d_present_[s] = nullptr; }
+        if (h_present_[s]) { (void)hipHostFree(h_present_[s]); h_present_[s] = nullptr; }
+        if (present_converted_[s]) { (void)hipEventDestroy(present_converted_[s]); present_converted_[s] = nullptr; }
+        if (present_copied_[s]) { (void)hipEventDestroy(present_copied_[s]); present_copied_[s] = nullptr; }
+    }
+    if (present_stream_) { (void)hipStreamDestroy(present_stream_); present_stream_ = nullptr; }
+    present_capacity_ = 0;
+    present_count_ = 0;
+}
+
+const uint8_t *RendererCore::presentRGBA8(const void *src_frame)
+{
+    requireDevice("presentRGBA8");
+    const size_t n = (size_t)framebuffer_size[0] * (size_t)framebuffer_size[1];
+    if (n == 0) throw std::runtime_error("presentRGBA8: setup() has not sized the framebuffer");
+    if (!src_frame) {
+        if (ext_fb_ && (fb_compact_ || fb_format_ == 1))
+            throw std::invalid_argument("presentRGBA8: the external target is compact and/or (grey, alpha): it does not hold fb_w x fb_h RGBA32F pixels");
+        src_frame = framebufferDevice();
+        if (!src_frame) throw std::runtime_error("presentRGBA8: no framebuffer");
+    }
+    if (present_capacity_ != n * 4) {
+        releasePresent();
+        check(hipStreamCreateWithFlags(&present_stream_, hipStreamNonBlocking), "hipStreamCreate(present)");
+        for (int s = 0; s < 2; s++) {
+            check(hipMalloc(&d_present_[s], n * 4), "hipMalloc(present)");
+            check(hipHostMalloc(reinterpret_cast<void **>(&h_present_[s]), n * 4, hipHostMallocDefault), "hipHostMalloc(present)");
+            check(hipEventCreateWithFlags(&present_converted_[s], hipEventDisableTiming), "hipEventCreate");
+            check(hipEventCreateWithFlags(&present_copied_[s], hipEventDisableTiming), "hipEventCreate");
+        }
+        present_capacity_ = n * 4;
+    }
+    const int s = present_count_ & 1;
+    // the slot's previous copy (two frames ago) must have left its staging buffer before it is overwritten
+    if (present_count_ >= 2) check(hipStreamWaitEvent(stream(), present_copied_[s], 0), "hipStreamWaitEvent");
+    check(launch_to_rgba8(src_frame, d_present_[s], n, stream()), "to_rgba8_kernel");
+    check(hipEventRecord(present_converted_[s], stream()), "hipEventRecord");
+    check(hipStreamWaitEvent(present_stream_, present_converted_[s], 0), "hipStreamWaitEvent");
+    check(hipMemcpyAsync(h_present_[s], d_present_[s], n * 4, hipMemcpyDeviceToHost, present_stream_), "hipMemcpy(D2H present)");
+    check(hipEventRecord(present_copied_[s], present_stream_), "hipEventRecord");
+    const int ready = present_count_ == 0 ? s : (s ^ 1);                  // the previous frame; the first call waits for its own
+    present_count_++;
+    check(hipEventSynchronize(present_copied_[ready]), "hipEventSynchronize");
+    return h_present_[ready];
 }
 
 // src/RendererCore.cpp:165-182: RGB8 read-back of the target, written top row first

@@ -54,6 +54,11 @@ public:
     bool checkRawInfFile(std::string fn);    // :46-54
     bool saveImage(std::string fn, std::string ext);  // :165-182
     void readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes);   // the own target converted on the device: 4x fewer bytes over PCIe
+    // Presentation (replaces the on-GPU blit of src/RendererCore.cpp:158-162 for a display that is not this GPU): the frame
+    // in `src_frame` (device RGBA32F, fb_w x fb_h; nullptr = this handle's target) is converted to RGBA8 on the launch
+    // stream and copied to one of TWO pinned host buffers on a copy stream; returns the frame enqueued by the PREVIOUS call
+    // (complete by now: its copy ran under the kernel that followed it), or this one after a wait on the first call.
+    const uint8_t *presentRGBA8(const void *src_frame);
     bool loadShader(std::string fn, bool reload);     // :112-136
 
     Camera main_cam;
@@ -144,6 +149,13 @@ private:
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
     void *d_rgba8_ = nullptr;                // RGBA8 staging of the target (readPixelsRGBA8)
     size_t rgba8_capacity_ = 0;
+    void *d_present_[2] = {nullptr, nullptr};    // presentRGBA8: device staging per slot
+    uint8_t *h_present_[2] = {nullptr, nullptr}; // ... and pinned host frames
+    hipEvent_t present_converted_[2] = {nullptr, nullptr}, present_copied_[2] = {nullptr, nullptr};
+    hipStream_t present_stream_ = nullptr;
+    size_t present_capacity_ = 0;
+    int present_count_ = 0;                  // frames enqueued so far
+    void releasePresent();
     void *d_vol12_ = nullptr;                // 12-bit packed copy of the bricked u16 volume (lazily, dropped with the volume)
     size_t vol12_bytes_ = 0;
     bool vol12_failed_ = false;              // allocation of the packed copy failed for this volume: do not retry

@@ -449,6 +449,13 @@ int vr_read_pixels_rgba8(vr_handle h, unsigned char *rgba8, size_t n_bytes)
     return guarded(h, [&](vr::RendererCore &c) { c.readPixelsRGBA8(rgba8, n_bytes); });
 }
 
+int vr_present_rgba8(vr_handle h, const unsigned char **frame)
+{
+    if (!frame) return VR_E_INVALID;
+    *frame = nullptr;
+    return guarded(h, [&](vr::RendererCore &c) { *frame = c.presentRGBA8(nullptr); });
+}
+
 int vr_save_image(vr_handle h, const char *path, const char *ext)
 {
     if (!h) return VR_E_INVALID;

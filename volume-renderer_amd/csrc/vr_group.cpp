@@ -459,4 +459,19 @@ int vr_group_read_pixels(vr_group_handle g, float *rgba, size_t n_floats)
     return VR_OK;
 }
 
+int vr_group_present_rgba8(vr_group_handle g, const unsigned char **frame)
+{
+    if (!g || !frame) return VR_E_INVALID;
+    *frame = nullptr;
+    const float4 *src = g->current >= 0 ? g->frame[g->current] : nullptr;
+    if (!src) return gfail(g, VR_E_INVALID, "vr_group_present_rgba8: no completed frame");
+    try {
+        VRG_HIP(hipSetDevice(g->devices[0]));
+        *frame = g->members[0]->core.presentRGBA8(src);
+    } catch (const std::exception &e) {
+        return gfail(g, VR_E_HIP, e.what());
+    }
+    return VR_OK;
+}
+
 }  // extern "C"

@@ -139,6 +139,8 @@ def load_library() -> C.CDLL:
         "vr_framebuffer_device": (C.c_void_p, [h]),
         "vr_read_pixels": (i32, [h, C.POINTER(f32), C.c_size_t]),
         "vr_read_pixels_rgba8": (i32, [h, C.c_void_p, C.c_size_t]),
+        "vr_present_rgba8": (i32, [h, C.POINTER(C.c_void_p)]),
+        "vr_group_present_rgba8": (i32, [h, C.POINTER(C.c_void_p)]),
         "vr_save_image": (i32, [h, C.c_char_p, C.c_char_p]),
         "vr_last_kernel_name": (C.c_char_p, [h]),
         "vr_read_pvm_volume": (C.c_void_p, [C.c_char_p] + [C.POINTER(C.c_uint)] * 4 + [C.POINTER(f32)] * 3),
@@ -277,6 +279,13 @@ class RendererGroup:
         out = np.zeros((h, w, 4), dtype=np.float32)
         self._check(self._lib.vr_group_read_pixels(self._g, _fp(out), out.size))
         return out
+
+    def presentRGBA8(self) -> np.ndarray:
+        """vr_group_present_rgba8: like RendererCore.presentRGBA8, of the assembled frame"""
+        w, h = self.framebuffer_size
+        ptr = C.c_void_p()
+        self._check(self._lib.vr_group_present_rgba8(self._g, C.byref(ptr)))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w, 4)).copy()
 
 
 class RendererCore:
@@ -580,6 +589,16 @@ class RendererCore:
         out = np.empty((h, w, 4), dtype=np.uint8)
         self._check(self._lib.vr_read_pixels_rgba8(self._h, out.ctypes.data, out.size))
         return out
+
+    def presentRGBA8(self, copy=True) -> np.ndarray:
+        """vr_present_rgba8: enqueue this frame's RGBA8 conversion + pinned D2H copy, return the PREVIOUS call's frame as
+        uint8 [H, W, 4] -- the first call returns its own frame.  copy=False: a view of the library's pinned buffer (valid
+        until the next-but-one call), what a GUI would hand to glTexImage2D"""
+        w, h = self.framebuffer_size
+        ptr = C.c_void_p()
+        self._check(self._lib.vr_present_rgba8(self._h, C.byref(ptr)))
+        view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w, 4))
+        return view.copy() if copy else view
 
     def saveImage(self, fn, ext) -> bool:
         rc = self._lib.vr_save_image(self._h, str(fn).encode(), ext.encode())
