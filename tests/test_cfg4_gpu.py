@@ -167,3 +167,69 @@ def test_big_offsets_every_mode_view_and_skipping_against_oracle(vra, oracle, cf
         cfg4.setSkipEmpty(False); cfg4.setMIP(False); cfg4.setTransferFunction(); cfg4.setAlpha(ALPHA)
         cfg4.setInitialCameraRotation(False, False)
         cfg4.setup((W, H))
+
+
+def test_cfg4_trilinear_staged_kernel_beyond_4gib(vra, oracle, cfg4, cfg4_host_volume):
+    """TRILINEAR on the 8 GiB volume (round 2: generic kernel only, >= 3 ms class): the LDS-staged kernel takes volumes
+    beyond 32-bit offsets (its apron copy is 10 GiB, DMA addresses are 64-bit) in every mode.  Full 4K frame: staged ==
+    generic bit for bit (grey composite and transfer function), equal sample counts; sparse rows against the oracle;
+    small full frames of every mode against the oracle."""
+    R = vra.renderer
+    r = cfg4
+    vol = cfg4_host_volume
+    try:
+        r.setFilter(R.FILTER_TRILINEAR)
+        for tf in (False, True):
+            if tf:
+                r.setTransferFunction(ISO, RGBA)
+            frames, counts, ms = {}, {}, {}
+            for name, variant in (("staged", 0), ("generic", 1)):
+                r.setKernelVariant(variant)
+                r.render(); r.kernelMsTake()
+                for _ in range(2):
+                    r.render()
+                ms[name] = r.kernelMsTake() / 2
+                assert r.last_kernel_name == ("raymarch_slab_tri_kernel" if name == "staged" else "raymarch_generic_kernel"), (name, r.last_kernel_name)
+                frames[name] = r.readPixels().copy()
+                counts[name] = r.countSamples()
+            print(f"cfg4 trilinear tf={tf}: staged {ms['staged']:.3f} ms, generic {ms['generic']:.3f} ms, apron copy {r.trilinearCopyBytes() / 2**30:.1f} GiB")
+            assert counts["staged"] == counts["generic"]
+            assert np.array_equal(bits(frames["staged"]), bits(frames["generic"])), tf
+        r.setKernelVariant(0)
+        tf_lut = r.getTransferLut()
+        p = oracle.OracleParams(W, H, cam=r.getCameraBlock(), alpha_scale=ALPHA, min_val=WINDOW[0], max_val=WINDOW[1], tf_rgba=tf_lut, filter=1, threads=1)
+        want = np.zeros((H, W, 4), dtype=np.float32)
+        got = frames["staged"]
+        for y in (274, 1080, 1885):
+            p.row_begin, p.row_end = y, y + 1
+            oracle.render(vol, p, out=want)
+            assert np.array_equal(bits(got[y]), bits(want[y])), f"cfg4 trilinear row {y}: max|diff|={np.abs(got[y] - want[y]).max()}"
+        # every mode at a small size, two cameras, against full oracle frames
+        w, h = 384, 216
+        r.setup((w, h))
+        for mode in ("grey", "mip", "tf", "mip_tf"):
+            mip, tf = "mip" in mode, "tf" in mode
+            alpha = 0.3 if mip else 0.01
+            r.setMIP(mip); r.setAlpha(alpha)
+            if tf:
+                r.setTransferFunction(ISO, RGBA)
+            else:
+                r.setTransferFunction()
+            lut = r.getTransferLut() if tf else None
+            r.resetCamera()
+            cams = [r.getCameraBlock()]
+            r.cameraOrient(0.0, 0.06 * 9, 0.06 * 13)
+            cams.append(r.getCameraBlock())
+            for ci, block in enumerate(cams):
+                r.setCameraBlock(block)
+                r.render()
+                assert r.last_kernel_name == "raymarch_slab_tri_kernel", (mode, ci)
+                got = r.readPixels()
+                total, spp = r.countSamples(per_pixel=True)
+                p = oracle.OracleParams(w, h, cam=block, alpha_scale=alpha, min_val=WINDOW[0], max_val=WINDOW[1], is_mip=int(mip), tf_rgba=lut, filter=1, threads=8)
+                want, want_total, want_spp = oracle.render(vol, p, want_spp=True)
+                assert total == want_total and np.array_equal(spp, want_spp), (mode, ci)
+                assert np.array_equal(bits(got), bits(want)), f"{mode} camera {ci}: max|diff|={np.abs(got - want).max()}"
+    finally:
+        r.setFilter(R.FILTER_NEAREST); r.setKernelVariant(0); r.setMIP(False); r.setTransferFunction(); r.setAlpha(ALPHA)
+        r.resetCamera(); r.setup((W, H))

@@ -485,6 +485,24 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 else off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
                 if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);   // odd x: upper 12 of the 16 bits
             }
+#if defined(VR_EXPERIMENTS) && defined(VR_X_COLS)
+            // timing only (WRONG voxels): VR_X_COLS wide loads per 8-sample batch instead of 8 narrow gathers -- what a
+            // "column along the ray" layout could buy on the L1 side (4 cycles per distinct line per gather INSTRUCTION)
+            if constexpr (ATAB && !BIG && PK12 && BATCH == 8) {
+                typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+                u2_t w = {0u, 0u};
+#pragma unroll
+                for (int u = 0; u < BATCH; u++) {
+                    if (u % (8 / VR_X_COLS) == 0) w = __builtin_amdgcn_raw_buffer_load_b64(rs12, (int)off[u], 0, 0);
+                    v[u] = (RawT)((u & 1 ? w.y : w.x) >> (4 * (u & 3)));
+                }
+                if (SPEC && !commit) {
+                    if (POW2) { Qx = Qx0; Qy = Qy0; Qz = Qz0; }
+                    else { qx = qx0; qy = qy0; qz = qz0; }
+                }
+                return false;
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (ATAB && !BIG) {
