@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=1024, help="synthetic volume edge (voxels)")
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="non-cubic synthetic volume NX NY NZ (overrides --volume)")
     ap.add_argument("--bytes", type=int, default=2, choices=(1, 2))
+    ap.add_argument("--synth", choices=("noise_ball", "sphere"), default="noise_ball",
+                    help="synthetic generator: the seeded noise ball (configs 2-4), or config 0/1's integer sphere (uint8, radius 7/16 of the edge)")
     ap.add_argument("--skip-empty", action="store_true", help="exact empty-space skipping (config 4)")
     ap.add_argument("--window", type=int, nargs=2, default=None, help="min max (default: full range of the generator)")
     ap.add_argument("--tf", action="store_true", help="default alpha-spline transfer function (config 4)")
@@ -244,7 +246,10 @@ def main():
         dims = tuple(r.dims[0])
         win = tuple(args.window) if args.window else r.window
     else:
-        r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
+        if args.synth == "sphere":
+            r.generateSynthetic(R.SYNTH_SPHERE_U8, dims, 1, dims[0] * 7 // 16)
+        else:
+            r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
         win = tuple(args.window) if args.window else (0, vmax)
     r.setWindow(*win)
     if args.tf:   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59), black->white ramp
@@ -683,7 +688,7 @@ def extras(args, r, local, stream, b, W, H):
         gbps = (s * b + W * H * 16) / (ms * 1e-3) / 1e9
         out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
                      "mpixels_per_s": round(W * H / ms / 1e3, 1), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4),
-                     "kernel": r.last_kernel_name}
+                     "kernel": r.last_kernel_name, "traffic": traffic_entry(name)}
 
     if args.extras:
         # PCIe-inclusive: kernel + D2H of the finished RGBA32F frame (vr_read_pixels), for DESIGN.md

@@ -1,0 +1,24 @@
+#!/bin/bash
+# HBM traffic (PMC: 2 * FETCH_SIZE + WRITE_SIZE, separate passes) of the configurations bench.py reports under `extras`,
+# written to profiles/traffic.json under the extras' names (keyed by the kernel-source hash like the headline's entry).
+#   gpurun --timeout 1800 -- tools/extras_traffic.sh
+set -u
+cd "$(dirname "$0")/.."; REPO=$PWD; export TMPDIR=/tmp
+run() {   # key, bench args...
+  KEY=$1; shift
+  OUT=$REPO/gpurun_out/traffic_$KEY; mkdir -p "$OUT"
+  CMD="python $REPO/bench.py --steps 6 --warmup 2 --clock-ramp-frames 20 --no-cpu-baseline --no-extras $*"
+  (cd /tmp; for C in FETCH_SIZE WRITE_SIZE; do
+     timeout -k 5 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- $CMD > "$OUT/$C.log" 2>&1
+   done)
+  python tools/summarize_profile.py "$OUT" "$KEY" > "$OUT/summary.txt" 2>&1
+  python tools/pmc_traffic.py "$OUT/summary.txt" "$KEY"
+}
+run cfg1_shape --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255
+run cfg2_shape_ert_window --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095
+run cfg4_grey --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004
+run cfg4_tf_skip --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --tf --skip-empty
+run trilinear_deep --filter trilinear
+run offaxis_deep --pose offaxis
+run headline_without_pack12 --no-pack12
+run shallow_alpha1_ert --alpha 1.0

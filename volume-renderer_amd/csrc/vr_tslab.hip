@@ -271,7 +271,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         corner[cidx][0] = gx - ex; corner[cidx][1] = gy - ey; corner[cidx][2] = gz - ez;
         if (cidx == 0) { corner[4][0] = ex; corner[4][1] = ey; corner[4][2] = ez; }
     }
-    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; }
+    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; }
     __syncthreads();
     float G[4][3], E[3];
 #pragma unroll
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             if (cL >= c_first - 1 && cL <= c_last + 3) {                 // layers some phase reads (L_p and L_p + 1) or prefetches
                 atomicMax(&red[3], dda);
                 atomicMax(&red[4], ddb);
+                if (amin - delta < 1.0f || bmin - delta < 1.0f) atomicOr(&red[5], 1);   // some ray comes within a voxel of a low face
             }
         }
     }
@@ -491,10 +492,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         };
         // (the weights are derived from ux, uy, uz by the caller AFTER the previous sample has used its own: no copies)
         float ux = 0.0f, uy = 0.0f, uz = 0.0f;
-        auto prepare = [&]() {
+        // CLAMP = false: the phase's samples are at least half a voxel away from the volume's low faces on every axis (the
+        // tile's corner rays say so for the minor axes, the layer index for the major one), so u = f - 0.5 >= 0 without
+        // the max (v_max_f32 issues at the slow rate: 3 x 4.4 of the loop's ~245 cycles)
+        auto prepare = [&](auto clamp_tag) {
+            constexpr bool CLAMP = decltype(clamp_tag)::value;
             float fx, fy, fz;
             scaled_here(fx, fy, fz);
-            ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f);
+            if (CLAMP) { ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f); }
+            else { ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f; }
             const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor: u >= 0
             lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> 2;
             uint32_t x0, xunused = 0, y0, y1, z0, z1;
@@ -505,12 +511,14 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             a00 = xz0 + y0; a10 = xz0 + y1; a01 = xz1 + y0; a11 = xz1 + y1;
         };
         auto weights = [&]() { wx = __builtin_amdgcn_fractf(ux); wy = __builtin_amdgcn_fractf(uy); wz = __builtin_amdgcn_fractf(uz); };   // == u - floor(u), exact: u >= 0
-        prepare(); weights();
+        prepare(std::true_type{}); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
+        const bool ahead_ok = LA >= 2;
+        const bool clamp_tile = uniform_i(red[5]) != 0;
         float takenf = 0.0f;
         const float limitf = (float)rem;
         for (int p = 0; p < n_phases; p++) {
-            const int L = L0 + sgn * p;
+            const int L = L0 + sgn * p, Lnext = L + sgn;
             // the layer that phase p + LA reads first
             const int n_new = issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
             // ---- this phase's samples: the ones whose cell lies in layer L.  The body is straight-line code for the whole
@@ -522,59 +530,72 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             // shader's test before every sample, VolumeRenderer.cs:118; dest.a never decreases).
             // (a second, select-free copy of the body for the iterations in which every lane has a sample -- four out of five --
             // measured SLOWER: 1.65 vs 1.51 ms; the look-ups issued at the end of one copy are consumed by either)
-            for (;;) {
-                const bool valid = takenf < limitf && lay == L && da < 0.95f;
-                if (!__any(valid ? 1 : 0)) break;
+            auto phase_samples = [&](auto clamp_tag) {
+                for (;;) {
+                    // RZ = 4: the layer BEHIND the two this phase reads is resident as well (requested two phases ago, landed before
+                    // the last barrier), so a ray may run one layer ahead of the phase: lanes whose own layer has 4 samples fill the
+                    // idle slot of the iteration that the 5-sample lanes need, and own a sample less in the next phase -- the
+                    // wavefront then takes ~4.1 iterations per layer instead of max(4, 5) = 5.  The phase still ends when no lane is
+                    // left IN layer L.
+                    const bool alive = takenf < limitf && da < 0.95f;
+                    const bool here = alive && lay == L;
+                    if (!__any(here ? 1 : 0)) break;
+                    const bool valid = here || (alive && lay == Lnext && ahead_ok);
 #if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-                st_iters++;
-                st_samples += valid ? 1 : 0;
+                    st_iters++;
+                    st_samples += valid ? 1 : 0;
 #endif
-                const float vf = valid ? 1.0f : 0.0f;
-                VR_LDS_AS const VoxelT *p00 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a00), *p10 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a10);
-                VR_LDS_AS const VoxelT *p01 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a01), *p11 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a11);
+                    const float vf = valid ? 1.0f : 0.0f;
+                    VR_LDS_AS const VoxelT *p00 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a00), *p10 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a10);
+                    VR_LDS_AS const VoxelT *p01 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a01), *p11 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a11);
 #if defined(VR_EXPERIMENTS) && defined(VR_X_NOTAPS)
-                const uint32_t v000 = a00 & 255u, v100 = a10 & 255u, v010 = a01 & 255u, v110 = a11 & 255u, v001 = (a00 >> 8) & 255u, v101 = (a10 >> 8) & 255u, v011 = (a01 >> 8) & 255u, v111 = (a11 >> 8) & 255u;
-                (void)p00; (void)p10; (void)p01; (void)p11;
+                    const uint32_t v000 = a00 & 255u, v100 = a10 & 255u, v010 = a01 & 255u, v110 = a11 & 255u, v001 = (a00 >> 8) & 255u, v101 = (a10 >> 8) & 255u, v011 = (a01 >> 8) & 255u, v111 = (a11 >> 8) & 255u;
+                    (void)p00; (void)p10; (void)p01; (void)p11;
 #else
-                const uint32_t v000 = p00[0], v100 = p00[1], v010 = p10[0], v110 = p10[1], v001 = p01[0], v101 = p01[1], v011 = p11[0], v111 = p11[1];
+                    const uint32_t v000 = p00[0], v100 = p00[1], v010 = p10[0], v110 = p10[1], v001 = p01[0], v101 = p01[1], v011 = p11[0], v111 = p11[1];
 #endif
-                // the next sample's position and table look-ups travel with the taps (a lane that did not advance prepares
-                // the same sample again: same values)
-                if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
-                else { qx = __builtin_fmaf(dsx, vf, qx); qy = __builtin_fmaf(dsy, vf, qy); qz = __builtin_fmaf(dsz, vf, qz); }
-                takenf += vf;
-                prepare();
-                const float ax = wx, ay = wy, az = wz;
-                const float c000 = (float)v000, c100 = (float)v100, c010 = (float)v010, c110 = (float)v110;
-                const float c001 = (float)v001, c101 = (float)v101, c011 = (float)v011, c111 = (float)v111;
-                const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-                const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-                const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-                float c, cg = 0.0f, cb = 0.0f, a;
-                classify(c0 + az * (c1 - c0), c, cg, cb, a);
-                if (MODE == 1) {
-                    da = (valid && da < a) ? a : da;
-                } else if (MODE == 3) {
-                    const bool take = valid && da < a;
-                    drgb = take ? c : drgb; dg = take ? cg : dg; db = take ? cb : db; da = take ? a : da;
-                } else {
-                    const float om = __builtin_fmaf(-da, vf, vf);       // (1 - dest.a) or 0: x + y * 0 == x, the sample of a lane that has none adds nothing
-                    drgb += c * om;
-                    if (MODE == 2) { dg += cg * om; db += cb * om; }
-                    da += a * om;
+                    // the next sample's position and table look-ups travel with the taps (a lane that did not advance prepares
+                    // the same sample again: same values)
+                    if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
+                    else { qx = __builtin_fmaf(dsx, vf, qx); qy = __builtin_fmaf(dsy, vf, qy); qz = __builtin_fmaf(dsz, vf, qz); }
+                    takenf += vf;
+                    prepare(clamp_tag);
+                    const float ax = wx, ay = wy, az = wz;
+                    const float c000 = (float)v000, c100 = (float)v100, c010 = (float)v010, c110 = (float)v110;
+                    const float c001 = (float)v001, c101 = (float)v101, c011 = (float)v011, c111 = (float)v111;
+                    const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+                    const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+                    const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+                    float c, cg = 0.0f, cb = 0.0f, a;
+                    classify(c0 + az * (c1 - c0), c, cg, cb, a);
+                    if (MODE == 1) {
+                        da = (valid && da < a) ? a : da;
+                    } else if (MODE == 3) {
+                        const bool take = valid && da < a;
+                        drgb = take ? c : drgb; dg = take ? cg : dg; db = take ? cb : db; da = take ? a : da;
+                    } else {
+                        const float om = __builtin_fmaf(-da, vf, vf);       // (1 - dest.a) or 0: x + y * 0 == x, the sample of a lane that has none adds nothing
+                        drgb += c * om;
+                        if (MODE == 2) { dg += cg * om; db += cb * om; }
+                        da += a * om;
+                    }
+                    weights();                                               // of the sample just prepared
                 }
-                weights();                                               // of the sample just prepared
-            }
+            };
+            // (L <= 2: with a ray running one layer ahead the sample prepared next may lie two layers on)
+            if (clamp_tile || L <= 2) phase_samples(std::true_type{});
+            else phase_samples(std::false_type{});
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
 #if !(defined(VR_EXPERIMENTS) && defined(VR_X_NOWAIT))
-            slab_wait_pieces(LA >= 2 ? uniform_i(n_new) : 0);
+            (void)n_new;
+            slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
 #endif
-            // every 4th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
+            // every 8th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
 #if defined(VR_EXPERIMENTS) && defined(VR_X_NOBAR)
             if ((p & 31) == 31) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
 #else
-            if ((p & 3) == 3) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
+            if ((p & 7) == 7) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
             else __syncthreads();
 #endif
         }
