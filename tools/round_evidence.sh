@@ -1,0 +1,25 @@
+#!/bin/bash
+# one GPU-box pass that refreshes everything the round's documents quote:
+#   gpurun --timeout 2400 -- tools/round_evidence.sh r03      then copy gpurun_out/evidence_<tag>/* into profiles/
+set -u
+TAG=${1:-final}
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/evidence_$TAG; mkdir -p $OUT
+# headline: rocprofv3 stats + PMC, HBM traffic keyed by the kernel-source hash
+tools/profile.sh ${TAG}_headline > $OUT/${TAG}_headline_summary.txt 2>&1
+python tools/pmc_traffic.py $OUT/${TAG}_headline_summary.txt 1024^3x2B_1920x1080_nearest_bricked_a0.004 > $OUT/traffic.log 2>&1
+cp gpurun_out/prof_${TAG}_headline/stats/*kernel_stats.csv $OUT/${TAG}_headline_kernel_stats.csv 2>/dev/null
+# TRILINEAR (the LDS-staged kernel): stats + PMC
+tools/profile.sh ${TAG}_trilinear --filter trilinear > $OUT/${TAG}_trilinear_summary.txt 2>&1
+cp gpurun_out/prof_${TAG}_trilinear/stats/*kernel_stats.csv $OUT/${TAG}_trilinear_kernel_stats.csv 2>/dev/null
+tools/pmc.sh ${TAG}_tslab_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32" -- --filter trilinear > $OUT/${TAG}_trilinear_sq.txt 2>&1
+# HBM traffic of every configuration bench.py reports under `extras`
+tools/extras_traffic.sh >> $OUT/traffic.log 2>&1
+cp profiles/traffic.json $OUT/traffic.json
+# the bench line (with extras), the native group on shared-device members, the torch path for comparison
+python bench.py --extras > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --native-group --gpus 4 --steps 50 > $OUT/bench_native_group4.json 2>&1
+VR_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 50 > $OUT/bench_torch_gloo4.json 2>&1
+tail -c 2500 $OUT/bench.json
+timeout 1500 python -m pytest tests -q -m gpu > $OUT/gputests.log 2>&1
+tail -3 $OUT/gputests.log

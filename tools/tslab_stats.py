@@ -28,7 +28,7 @@ v = st[m]
 staged, rz, slots, phases = v & 1, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 4095
 print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}); RZ histogram {np.bincount(rz)[:6]}; "
       f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
-      f"RA*RB of unstaged tiles {np.unique(slots[staged == 0])[:20]}; phases mean {phases.mean():.1f} max {phases.max()}")
+      f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
 clk, wall, iters, samp = spp[::16, 1::32][m].astype(np.float64), spp[::16, 2::32][m].astype(np.float64), spp[::16, 3::32][m].astype(np.float64), spp[::16, 4::32][m].astype(np.float64)
 ok = wall > 0
 print(f"staged loop per tile: {clk[ok].mean():.0f} shader-clock ticks in {wall[ok].mean() / 100:.1f} us -> {np.median(clk[ok] / wall[ok]) * 100 / 1e3:.3f} GHz (median over tiles); wavefront 0: {iters[ok].sum():.0f} iterations for {samp[ok].sum():.0f} lane-0 samples ({iters[ok].sum() / max(samp[ok].sum(), 1):.3f} iterations per sample of lane 3)")
