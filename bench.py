@@ -74,7 +74,7 @@ def parse_args():
                     help="N > 1: gather the shards to rank 0 (default: the frame is needed in one place, like the reference's "
                          "single framebuffer; RCCL send/recv over rank 0's point-to-point links) or all_gather them to every rank")
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
-    ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 fast kernel with the plain loop, 3 always relay, 4 LDS-staged slab kernel, 5 fast kernel with the pipelined loop)")
+    ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 fast kernel with the plain loop, 3 always relay, 5 fast kernel with the pipelined loop)")
     ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
     ap.add_argument("--shard", type=int, nargs=2, default=None, metavar=("WORLD", "RANK"),
                     help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")

@@ -152,9 +152,9 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    relay kernel; the fast kernel runs its software-pipelined batch loop unless alpha_scale >= 0.5),
    1 = always the generic line-by-line kernel (cross-check / debugging), 2 = the fast kernel with its
    plain loop: never the relay kernel, never the pipelined loop, 3 = automatic but always the relay kernel
-   when the shape allows, 4 = the LDS-staged kernel (bricks streamed into LDS by LDS-DMA, vr_slab.hip)
-   wherever it is eligible -- bit-identical frames; measured slower than the default kernels on MI355X
-   (DESIGN.md section 6), kept as an opt-in, 5 = the fast kernel with the pipelined loop, never the relay,
+   when the shape allows, 4 = retired (the NEAREST LDS-staged kernel of round 2 lost to the default kernels in every
+   cell of the round-3 sweep, profiles/r03_work_model_sweep.txt, and was deleted; the value is refused),
+   5 = the fast kernel with the pipelined loop, never the relay,
    6 = TRILINEAR on the LDS-staged kernel (the apron copy's bricks streamed into LDS, eight ds_read taps per
    sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible.
    Frames are bit-identical under every variant. */

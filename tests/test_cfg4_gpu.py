@@ -20,7 +20,7 @@ ISO = [0, 141, 149, 255]                      # the widget's default alpha knots
 RGBA = [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]]
 WINDOW = (8, 255)                             # voxels <= 8 classify to zero: the corners outside the ball are skippable
 ALPHA = 0.004
-SPECIALISED = ("raymarch_fast_kernel", "raymarch_relay_kernel", "raymarch_slab_kernel")
+SPECIALISED = ("raymarch_fast_kernel", "raymarch_relay_kernel")
 
 
 def bits(a):

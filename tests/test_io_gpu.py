@@ -65,7 +65,7 @@ def test_cfg2_sized_raw_file_through_the_reference_default_pipeline(vra, oracle,
         assert (lo, hi) == (int(vol.min()), int(vol.max())) == r.dataset_range
         r.setAlpha(0.05)
         r.render()
-        assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_relay_kernel", "raymarch_slab_kernel")
+        assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_relay_kernel")
         got = r.readPixels()
         block = r.getCameraBlock()
     p = oracle.OracleParams(W, H, cam=block, alpha_scale=0.05, min_val=lo + 1000, max_val=hi + 1000, threads=0)

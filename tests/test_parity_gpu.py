@@ -11,7 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
-FAST_KERNELS = ("raymarch_fast_kernel", "raymarch_relay_kernel", "raymarch_slab_kernel")   # relay = sparse launches; slab = LDS-staged bricks
+FAST_KERNELS = ("raymarch_fast_kernel", "raymarch_relay_kernel")   # relay = sparse launches
 
 
 def make_renderer(vra, size, **kw):
@@ -754,14 +754,17 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
         lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
         alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
-        mip = tf = tri = accum = relay = stripes = slab = pipe = False
+        mip = tf = tri = accum = relay = stripes = pipe = tslab = batched = False
+        renders = 1
         if extended:
-            mode = int(rng.integers(0, 16))
-            mip, tf, tri, accum = mode in (1, 8, 13), mode in (2, 8, 14), mode == 3, mode == 4     # 8: MIP through the transfer function
+            mode = int(rng.integers(0, 24))
+            mip, tf, tri, accum = mode in (1, 8, 13, 17, 19), mode in (2, 8, 14, 18, 19), mode in (3, 16, 17, 18, 19, 20, 21, 23), mode == 4     # 8: MIP through the transfer function
             relay = mode in (5, 6)
-            stripes = mode in (7, 15)
-            slab = mode in (12, 13, 14, 15)       # the LDS-staged kernel (opt-in variant 4) wherever the trial is eligible for it
+            stripes = mode in (7, 15, 21)
             pipe = mode in (9, 10)                # the fast kernel's software-pipelined loop (variant 5) instead of relay / plain loop
+            tslab = mode in (16, 17, 21)          # round 3: TRILINEAR on the LDS-staged layer-synchronous kernel (variant 6); 18, 19: with a transfer function
+            batched = mode == 20                  # ... and the batched trilinear kernel (variant 2)
+            renders = 5 if mode in (22, 23) else (3 if mode in (12, 13, 14, 15) else 1)    # the measured work model: repeated frames per camera try its candidate kernels (12..15 were the retired NEAREST LDS-staged kernel's modes)
             if rng.random() < 0.2:
                 W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
         tf_lut = None
@@ -792,10 +795,12 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 r.setAccum(1)
             if relay:
                 r.setKernelVariant(3)
-            if slab:
-                r.setKernelVariant(4)
             if pipe:
                 r.setKernelVariant(5)
+            if tslab:
+                r.setKernelVariant(6)
+            if batched:
+                r.setKernelVariant(2)
             rows = None
             if stripes:
                 rows = (4, int(rng.integers(0, 3)), 3)
@@ -805,15 +810,20 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 if rng.random() < 0.25:                       # axis-parallel rays (zero direction components)
                     block = oracle.default_camera_block(); block[16:19] = block[12:15] = (rng.uniform(-0.4, 0.4), 0.0, 3.0)
                 r.setCameraBlock(block)
+                for _k in range(renders - 1):                  # earlier frames of the exploration: kept for the comparison below
+                    r.render()
+                    first = r.readPixels().copy() if _k == 0 else first
                 r.render()
                 got = r.readPixels()
+                if renders > 1:
+                    assert np.array_equal(first.view(np.uint32), got.view(np.uint32)), "frames of the work model's exploration differ"
                 _, spp = r.countSamples(per_pixel=True)
                 p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo + win_off, max_val=hi + win_off,
                                         view_top=int(top), view_bottom=int(bottom), is_mip=int(mip), filter=int(tri),
                                         accum=int(accum), tf_rgba=tf_lut, trunc_grid=quirks & 1)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
                 what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
-                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} slab {slab} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} slab {slab} tslab {tslab} batched {batched} renders {renders} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
                 if rows:                                       # only this shard's rows are rendered
                     mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
                     assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)
@@ -899,7 +909,7 @@ def test_relay_kernel_equals_fast_kernel(vra, oracle, variant):
                 for name, block in orbit_blocks(oracle):
                     r.setCameraBlock(block)
                     r.render()
-                    assert r.last_kernel_name == "raymarch_relay_kernel" if variant == 3 else r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_slab_kernel")
+                    assert r.last_kernel_name == "raymarch_relay_kernel" if variant == 3 else r.last_kernel_name == "raymarch_fast_kernel"
                     got = r.readPixels()
                     _, spp = r.countSamples(per_pixel=True)
                     p = oracle.OracleParams(120, 88, cam=block, alpha_scale=alpha, min_val=win[0], max_val=win[1],
@@ -965,7 +975,7 @@ def test_relay_kernel_full_size_shard(vra, cfg3):
     for _ in range(5):
         r.render()
     t_fast = r.kernelMsTake() / 5
-    assert r.last_kernel_name in ("raymarch_fast_kernel", "raymarch_slab_kernel")
+    assert r.last_kernel_name == "raymarch_fast_kernel"
     fast = r.readPixels()
     r.setKernelVariant(0)
     for _ in range(12):                                       # the measured work model tries its candidates, then settles
@@ -1107,7 +1117,7 @@ def _first_sample_outside(block, W, H):
     return int((hit & outside).sum())
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4, 5], ids=["auto", "fast", "relay", "slab", "pipelined"])
+@pytest.mark.parametrize("variant", [0, 2, 3, 5], ids=["auto", "fast", "relay", "pipelined"])
 def test_rays_that_end_inside_their_checked_head(vra, oracle, variant):
     """round-2 advisor finding: the relay kernel composited its prefix batches and tail onto rays whose first sample
     fails the bounds test (the shader, and every other kernel, end such a ray with zero samples).  Far cameras make

@@ -1,4 +1,4 @@
-"""TRILINEAR on the LDS-staged kernel (vr_slab.hip with TRI; vr_set_kernel_variant(6), and the automatic choice for
+"""TRILINEAR on the LDS-staged kernel (vr_tslab.hip; vr_set_kernel_variant(6), and the automatic choice for
 views aligned with a volume axis) against the CPU oracle, the batched trilinear kernel and the generic kernel.
 
 What differs from every other trilinear path: the eight taps of a sample are LDS reads from a torus of apron-copy

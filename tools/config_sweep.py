@@ -12,6 +12,7 @@ R = vra.renderer
 which = (sys.argv[1] if len(sys.argv) > 1 else "cfg1,cfg2,cfg3,cfg4").split(",")
 worlds = [int(w) for w in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
 nposes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+VARIANTS = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (2, 5, 3, 0)   # e.g. 2,5,3,4,0 adds the LDS-staged NEAREST kernel
 CFG = {  # name: (dims, bytes, (W, H), window, alpha, tf + skip)
     "cfg1": ((256, 256, 256), 1, (1280, 720), (0, 255), 1.0, False),
     "cfg2": ((512, 512, 452), 2, (1920, 1080), (1000, 5095), 0.05, False),
@@ -53,10 +54,10 @@ for name in which:
             if pose:
                 r.cameraOrient(*pose)
             row = {}
-            for v in (2, 5, 3, 0):
+            for v in VARIANTS:
                 r.setKernelVariant(v)
                 row[v] = (ms(), r.last_kernel_name.replace("raymarch_", "").replace("_kernel", ""))
-            best = min(row[v][0] for v in (2, 5, 3))
+            best = min(row[v][0] for v in VARIANTS if v != 0)
             gap = row[0][0] / best - 1.0
             flag = "  <-- auto %.1f %% behind" % (100 * gap) if gap > 0.03 else ""
             if gap > 0.03:

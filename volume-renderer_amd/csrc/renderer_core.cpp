@@ -618,7 +618,6 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    L.slab_allowed = force_generic == 4 ? 1 : 0;             // kernel variant 4: the LDS-staged kernel wherever it is eligible
     L.tri_slab = force_generic == 6 ? 1 : 0;                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
     L.pipelined = 0;
     L.short_batches = 0;
@@ -967,7 +966,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // on the configuration the 256 / 1024 were measured on; a 256^3 volume's 262-sample rays want 4x fewer tiles)
     const double len_scale = std::min(1.0, std::max(0.15, tile_longest_ / 1000.0));
     L.sparse_shard = ((double)tile_active_ < (aligned ? 256.0 : 1024.0) * len_scale) ? 1 : 0;
-    if (force_generic == 2 || force_generic == 4) L.sparse_shard = 0;   // kernel variants 2, 4: never the relay kernel
+    if (force_generic == 2) L.sparse_shard = 0;   // kernel variant 2: never the relay kernel
     if (force_generic == 3) L.sparse_shard = 1;          // kernel variant 3: always (when the shape allows)
     L.pipelined = (force_generic == 0 && P.alpha_scale < 0.5f) ? 1 : 0;
     L.short_batches = (force_generic == 0 && P.alpha_scale >= 0.5f) ? 1 : 0;     // 0.174 vs 0.190 ms at alpha = 1 (cfg3)

@@ -1,5 +1,5 @@
 // vr_device.h -- device-side helpers shared by the ray-march translation units
-// (vr_kernels.hip, vr_slab.hip): GLSL built-ins restated, ray set-up, the slab test, voxel
+// (vr_kernels.hip, vr_tslab.hip): GLSL built-ins restated, ray set-up, the slab test, voxel
 // addressing, the safe-prefix bound.  See vr_kernels.hip for the arithmetic contract.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -83,10 +83,9 @@ struct LaunchConfig {
     uint32_t tile_table_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
-    int slab_allowed;              // use the LDS-staged kernel where eligible (vr_set_kernel_variant 4; off by default)
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_slab.hip; host: aligned views, vr_set_kernel_variant 6 forces it)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip; host: aligned views, vr_set_kernel_variant 6 forces it)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

@@ -12,11 +12,7 @@ bool fast_path_eligible(const FrameParams &P, const LaunchConfig &L);
 // TRILINEAR in a grey mode with everything the batched trilinear kernel needs except the tile table
 bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L);
 
-// true when (P, L) runs on the LDS-staged kernel (vr_slab.hip): a fast-path configuration on the bricked
-// layout with u8 voxels or the 12-bit packed copy, a classification table, torus tables that fit
-bool slab_path_eligible(const FrameParams &P, const LaunchConfig &L);
-
-// TRILINEAR on the LDS-staged kernel (vr_slab.hip, TRI): the trilinear path's preconditions with any mode (grey, MIP,
+// TRILINEAR on the LDS-staged kernel (vr_tslab.hip): the trilinear path's preconditions with any mode (grey, MIP,
 // transfer function), the bricked layout with its apron copy resident, torus tables that fit LDS; volumes beyond
 // 32-bit offsets included
 bool tri_slab_candidate(const FrameParams &P, const LaunchConfig &L);

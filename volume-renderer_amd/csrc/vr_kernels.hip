@@ -1766,31 +1766,9 @@ bool tri_path_candidate(const FrameParams &P, const LaunchConfig &L)
            !L.big_offsets && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX;
 }
 
-// The LDS-staged kernel (vr_slab.hip) takes the fast path's configurations whose voxels it can stage: the
-// bricked layout with u8 voxels (64-byte bricks) or the 12-bit packed copy of a u16 volume (96-byte bricks),
-// a window that fits its classification table, per-axis tables that fit LDS, a tile table.  Sparse launches
-// keep the relay kernel; exact empty-space skipping stays with the fast kernel.
-bool slab_path_eligible(const FrameParams &P, const LaunchConfig &L)
-{
-    if (!fast_path_eligible(P, L) || !L.slab_allowed || L.layout != 1 || !L.use_lut || !L.tile_table) return false;
-    if (P.skip_empty != 0 && L.skip_grid != nullptr) return false;
-    const int64_t width = (int64_t)P.max_val - (int64_t)P.min_val + 1;
-    const uint64_t bricks = (uint64_t)P.bnx * (uint64_t)P.bny * (uint64_t)P.bnz;
-    if (bricks >= (1ull << 32) || (uint64_t)P.bnx * (uint64_t)P.bny >= (1ull << 24)) return false;
-    if (L.bytes_per_voxel == 1) return width <= 256 && P.nx + P.ny + P.nz <= 6144;
-    return L.packed12 != nullptr && width <= 4096 && P.nx + P.ny + P.nz <= 3072;
-}
-
-static bool slab_selected(const FrameParams &P, const LaunchConfig &L) { return slab_path_eligible(P, L) && !relay_selected(P, L); }
-
-hipError_t launch_raymarch_slab_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                   uint32_t *spp, hipStream_t st);
-hipError_t launch_raymarch_slab_pk12(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                     uint32_t *spp, hipStream_t st);
-
 static bool tri_path_eligible(const FrameParams &P, const LaunchConfig &L) { return tri_path_candidate(P, L) && L.tile_table != nullptr; }
 
-// TRILINEAR on the LDS-staged kernel (vr_slab.hip): every mode (the 256-entry transfer-function table sits in LDS), any
+// TRILINEAR on the LDS-staged kernel (vr_tslab.hip): every mode (the 256-entry transfer-function table sits in LDS), any
 // volume size (64-bit DMA addresses), the bricked layout; the apron copy must be resident (host: refreshApron)
 bool tri_slab_candidate(const FrameParams &P, const LaunchConfig &L)
 {
@@ -1842,13 +1820,10 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
         return L.bytes_per_voxel == 1 ? launch_raymarch_slab_tri_u8(P, L, vol, tf, fb, spp, st) : launch_raymarch_slab_tri_u16(P, L, vol, tf, fb, spp, st);
     }
     const int fast = fast_path_eligible(P, L) ? 1 : (tri_path_eligible(P, L) ? 2 : 0);
-    const bool slab = fast == 1 && slab_selected(P, L);
     if (kernel_name)
         *kernel_name = fast == 0 ? "raymarch_generic_kernel"
                                  : (fast == 2 ? "raymarch_tri_kernel"
-                                              : (slab ? "raymarch_slab_kernel" : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel")));
-    if (slab)
-        return L.bytes_per_voxel == 1 ? launch_raymarch_slab_u8(P, L, vol, tf, fb, spp, st) : launch_raymarch_slab_pk12(P, L, vol, tf, fb, spp, st);
+                                              : (relay_selected(P, L) ? "raymarch_relay_kernel" : "raymarch_fast_kernel"));
     const int tu = (L.bytes_per_voxel == 1 ? 0 : 2) + (L.layout == 0 ? 0 : 1);
 #if VR_TU == -1
     switch (tu) {

@@ -1,4 +1,4 @@
-// vr_lds_dma.h -- gfx950 helpers shared by the LDS-staged ray-march kernels (vr_slab.hip, vr_tslab.hip):
+// vr_lds_dma.h -- gfx950 helpers shared by the LDS-staged ray-march kernel (vr_tslab.hip):
 // LDS-DMA (global_load_lds_dwordx4 through M0), explicit vmcnt waits, wave-uniform values, DPP reductions.
 #pragma once
 #include <hip/hip_runtime.h>
