@@ -156,7 +156,9 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    cell of the round-3 sweep, profiles/r03_work_model_sweep.txt, and was deleted; the value is refused),
    5 = the fast kernel with the pipelined loop, never the relay,
    6 = TRILINEAR on the LDS-staged kernel (the apron copy's bricks streamed into LDS, eight ds_read taps per
-   sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible.
+   sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible,
+   7 = that kernel with staging switched off: every tile takes the path of tiles whose brick layers do not fit LDS
+   (pair loads from the apron copy, four samples' taps in flight) -- the cross-check of that path.
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): under kernel variant 0 the launch is a MEASURED choice -- every candidate kernel of a configuration

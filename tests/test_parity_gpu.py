@@ -645,7 +645,7 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
 
 
 def test_long_axis_volume_without_address_tables(vra, oracle):
-    """nx + ny + nz > 3072: the LDS address tables (and with them the packed copy and the trilinear
+    """nx + ny + nz > 3072: the LDS address tables (and with them the packed copy and the batched trilinear
     kernel) do not apply; the specialised kernels compute brick addresses arithmetically"""
     rng = np.random.default_rng(3072)
     R = vra.renderer
@@ -668,8 +668,8 @@ def test_long_axis_volume_without_address_tables(vra, oracle):
                                     filter=int(filt == R.FILTER_TRILINEAR), is_mip=int(mip))
             want, _, want_spp = oracle.render(vol, p, want_spp=True)
             assert_same(got, want, spp, want_spp, what=f"long-axis volume layout {layout} filter {filt} mip {mip} kernel {kernel}")
-            if filt == R.FILTER_TRILINEAR:
-                assert kernel == "raymarch_generic_kernel"
+            if filt == R.FILTER_TRILINEAR:       # bricked: the LDS-staged kernel's plan and tables cover a tile's own index ranges only (round 3)
+                assert kernel == ("raymarch_slab_tri_kernel" if layout == R.LAYOUT_BRICKED else "raymarch_generic_kernel")
             else:
                 assert kernel in FAST_KERNELS
 
@@ -823,7 +823,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                                         accum=int(accum), tf_rgba=tf_lut, trunc_grid=quirks & 1)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
                 what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
-                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} slab {slab} tslab {tslab} batched {batched} renders {renders} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} tslab {tslab} batched {batched} renders {renders} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
                 if rows:                                       # only this shard's rows are rendered
                     mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
                     assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)

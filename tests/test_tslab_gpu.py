@@ -58,8 +58,9 @@ def cameras(oracle, rng, n_random=3):
                                           ((40, 56, 24), (0.6, 1.0, 1.3)), ((7, 5, 3), (1, 1, 1)), ((1, 1, 1), (1, 1, 1)),
                                           ((2, 9, 4), (1, 1, 1)), ((256, 256, 256), (1, 1, 1))],
                          ids=["cube64", "noncubic", "odd_dims", "aniso", "tiny", "one_voxel", "thin", "cube256"])
-def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing):
-    rng = np.random.default_rng(abs(hash((dims, np.dtype(dtype).name, "tri"))) % (2 ** 32))
+@pytest.mark.parametrize("variant", [6, 7], ids=["staged", "unstaged"])      # 7: every tile on the path of tiles that do not fit LDS
+def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing, variant):
+    rng = np.random.default_rng((sum(d * 31 ** k for k, d in enumerate(dims)) * 7 + np.dtype(dtype).itemsize) % (2 ** 32))
     vol = rand_volume(rng, dims, dtype, smooth=dims[0] >= 96)
     vmax = 255 if dtype == np.uint8 else 4095
     size = (200, 144) if dims[0] < 256 else (320, 200)
@@ -76,7 +77,7 @@ def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing):
             r.setAlpha(alpha)
             for name, block in cameras(oracle, rng):
                 r.setCameraBlock(block)
-                r.setKernelVariant(6)                            # TRILINEAR on the LDS-staged kernel wherever it is eligible
+                r.setKernelVariant(variant)                      # TRILINEAR on the LDS-staged kernel wherever it is eligible
                 r.render()
                 seen.add(r.last_kernel_name)
                 got = r.readPixels()
@@ -92,7 +93,8 @@ def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing):
 
 @pytest.mark.parametrize("mode", ["mip", "tf", "mip_tf", "top", "bottom", "mip_top", "tf_bottom"])
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
-def test_tri_slab_kernel_modes_and_views(vra, oracle, dtype, mode):
+@pytest.mark.parametrize("variant", [6, 7], ids=["staged", "unstaged"])
+def test_tri_slab_kernel_modes_and_views(vra, oracle, dtype, mode, variant):
     rng = np.random.default_rng(5)
     dims, spacing = (72, 64, 80), (1.0, 1.0, 1.0)
     vol = rand_volume(rng, dims, dtype, smooth=True)
@@ -116,7 +118,7 @@ def test_tri_slab_kernel_modes_and_views(vra, oracle, dtype, mode):
             r.setTransferFunction([0, 90, 160, 255], [[0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
             tf_lut = r.getTransferLut()
         r.setInitialCameraRotation(top, bottom)
-        r.setKernelVariant(6)
+        r.setKernelVariant(variant)
         for name, block in cameras(oracle, rng, n_random=2):
             r.setCameraBlock(block)
             r.render()
@@ -128,6 +130,31 @@ def test_tri_slab_kernel_modes_and_views(vra, oracle, dtype, mode):
             want, want_total, want_spp = oracle.render(vol, p, want_spp=True)
             assert total == want_total and np.array_equal(spp, want_spp), (mode, name)
             assert np.array_equal(bits(got), bits(want)), f"{mode} {name}: max|diff|={np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("dims", [(4, 6, 10400), (10400, 5, 4), (3, 10400, 8)], ids=["long_z", "long_x", "long_y"])
+def test_tri_slab_unstaged_tiles_of_a_very_long_volume(vra, oracle, dims):
+    """an axis so long that the unstaged path's per-axis offset tables (8 bytes per z index) do not fit LDS: those tiles
+    fall back to the shader's literal taps from the resident volume; staged tiles (variant 6) keep range-restricted tables"""
+    rng = np.random.default_rng(77)
+    vol = rand_volume(rng, dims, np.uint8)
+    spacing = tuple(float(v) for v in (64.0 / np.array(dims)))          # a cube in world units
+    size = (128, 96)
+    R = vra.renderer
+    with vra.RendererCore(0) as r:
+        r.setup(size)
+        assert r.loadShader("VolumeRenderer.cs")
+        r.setQuirks(0); r.setVolume(vol, spacing); r.setFilter(R.FILTER_TRILINEAR); r.setWindow(0, 255); r.setAlpha(0.05)
+        for name, block in cameras(oracle, rng, n_random=1)[:5]:
+            p = oracle.OracleParams(size[0], size[1], cam=block, alpha_scale=0.05, voxel_size=spacing, min_val=0, max_val=255, filter=1, threads=8)
+            want, want_total, want_spp = oracle.render(vol, p, want_spp=True)
+            for variant in (6, 7):
+                r.setCameraBlock(block); r.setKernelVariant(variant); r.render()
+                assert r.last_kernel_name == TSLAB
+                got = r.readPixels()
+                total, spp = r.countSamples(per_pixel=True)
+                assert total == want_total and np.array_equal(spp, want_spp), (dims, name, variant)
+                assert np.array_equal(bits(got), bits(want)), f"{dims} {name} variant {variant}: max|diff|={np.abs(got - want).max()}"
 
 
 def test_tri_slab_equals_batched_kernel_on_shards_and_quirks(vra):

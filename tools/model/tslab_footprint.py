@@ -67,7 +67,7 @@ for ty in range(tiles_y):
         g0 = np.abs(G[0]); m = int(np.argmax(g0))
         gm = G[:, m]; gmax = np.abs(G).max(axis=1)
         if not (np.all(gm >= 0.3 * gmax) or np.all(-gm >= 0.3 * gmax)):
-            res.append((0, 0, 0, 0, 0)); continue
+            res.append((0, 0, 0, 0, 0, 0, 0)); continue
         a_ax, b_ax = (1 if m == 0 else 0), (1 if m == 2 else 2)
         tin, tout = np.max(np.where(tmax > tmin, tmin, -np.inf)), np.max(np.where(tmax > tmin, tmax, -np.inf))
         fm_in = np.clip(E[m] + G[:, m] * np.maximum(tmin, 0), 0, N); fm_out = np.clip(E[m] + G[:, m] * tmax, 0, N)
@@ -100,7 +100,33 @@ for ty in range(tiles_y):
         lo_c = np.floor((C.min(1) - (0.5 + delta) * (1 + abs(s))) / 4 - abs(s) * 0.75 - 1).astype(int)
         hi_c = np.floor((C.max(1) + (0.5 + delta) * (1 + abs(s))) / 4 + abs(s) * 0.75 + 1).astype(int)
         ra_s, rb_s = int((hi_c - lo_c).max()) + 1, int((hi_p - lo_p).max()) + 1
-        res.append((1, ra_r, rb_r, ra_s, rb_s))
+        # per-row extents: hull of the frustum slab's projection = its 12 edges (4 per plane + 4 along the corner rays)
+        pairs = [(0, 1), (1, 3), (3, 2), (2, 0), (4, 5), (5, 7), (7, 6), (6, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+        ra_t = rb_t = 0
+        for li in range(0, len(Ls), max(1, len(Ls) // 24)):          # a sample of the layers (the far ones are the largest)
+            a8, b8 = A[li], B[li]
+            mrg = 0.5 + delta
+            rows = range(int(np.floor(b8.min() - mrg)) >> 2, (int(np.floor(b8.max() + mrg)) >> 2) + 1)
+            wmax = 0
+            for rb in rows:
+                y0, y1 = 4 * rb - mrg, 4 * rb + 4 + mrg            # taps of this brick row come from positions within the margin of it
+                lo, hi = np.inf, -np.inf
+                for (u, v) in pairs:
+                    bu, bv, au, av = b8[u], b8[v], a8[u], a8[v]
+                    t0, t1 = 0.0, 1.0
+                    if bu == bv:
+                        if not (y0 <= bu <= y1): continue
+                    else:
+                        ta, tb = (y0 - bu) / (bv - bu), (y1 - bu) / (bv - bu)
+                        t0, t1 = max(0.0, min(ta, tb)), min(1.0, max(ta, tb))
+                        if t0 > t1: continue
+                    for t in (t0, t1):
+                        a = au + t * (av - au); lo = min(lo, a); hi = max(hi, a)
+                if hi < lo: continue
+                w = (int(np.floor(hi + mrg)) >> 2) - (int(np.floor(lo - mrg)) >> 2) + 1
+                wmax = max(wmax, w)
+            ra_t, rb_t = max(ra_t, wmax), max(rb_t, len(rows))
+        res.append((1, ra_r, rb_r, ra_s, rb_s, ra_t, rb_t))
 res = np.array(res)
 ok = res[:, 0] == 1
 rect = res[ok, 1] * res[ok, 2]; shear = res[ok, 3] * res[ok, 4]
@@ -108,5 +134,7 @@ lim = min(LAYER_MAX, slots_avail // 3)
 print(f"tiles hitting the box {len(res)}, with an agreed major axis {ok.sum()}")
 print(f"rectangles: slots percentiles 10/50/90/100 {np.percentile(rect, [10, 50, 90, 100])}; fit {np.mean(rect <= lim):.3f}")
 print(f"sheared   : slots percentiles 10/50/90/100 {np.percentile(shear, [10, 50, 90, 100])}; fit {np.mean(shear <= lim):.3f}; best of both fit {np.mean(np.minimum(rect, shear) <= lim):.3f}")
-for f in (0.5, 0.75):
+tight = res[ok, 5] * res[ok, 6]
+print(f"row-tight : slots percentiles 10/50/90/100 {np.percentile(tight, [10, 50, 90, 100])}; fit {np.mean(tight <= lim):.3f}; RA p50/max {np.percentile(res[ok, 5], 50)}/{res[ok, 5].max()}, RB p50/max {np.percentile(res[ok, 6], 50)}/{res[ok, 6].max()}")
+for f in ():
     print(f"  with {f:.2f} of the tile (a {int(32 * f)}x16 tile would need about): rect fit {np.mean(rect * (f + (1 - f) * 0.4) <= lim):.3f} (crude)")

@@ -7,8 +7,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 vra = importlib.import_module("volume-renderer_amd")
 R = vra.renderer
 r = vra.RendererCore(0)
-r.setup((1920, 1080)); r.loadShader("x"); r.setQuirks(0)
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+r.setup((1920, 1080) if N <= 1024 else (3840, 2160)); r.loadShader("x"); r.setQuirks(0)
 b = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
 r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
@@ -29,4 +29,11 @@ out = {"default": ms()}
 if poses == "both":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
     out["offaxis"] = ms(10)
+elif poses.startswith("orbit"):
+    rng = np.random.default_rng(7)
+    for k in range(int(poses[5:] or 6)):
+        r.resetCamera()
+        ze, az = float(rng.uniform(-1.2, 1.2)), float(rng.uniform(-3, 3))
+        r.cameraOrient(0.0, ze, az)
+        out[f"ze{ze:+.2f}az{az:+.2f}"] = ms(10)
 print(r.last_kernel_name, {k: round(v, 4) for k, v in out.items()})

@@ -18,6 +18,8 @@ r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
 r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
 if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
+elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
+    r.cameraOrient(0.0, *[float(v) for v in pose.split(",")])
 r.setKernelVariant(6)
 r.render()
 print("kernel", r.last_kernel_name)
@@ -26,11 +28,16 @@ st = spp[::16, ::32]
 m = (st & 0x80000000) != 0
 v = st[m]
 staged, rz, slots, phases = v & 1, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 4095
+print("why not staged (1 corner rays disagree on / graze the major axis, 2 layer above the DMA piece limit, 3 ring not three layers deep, 4 layer beyond 64 KiB):", np.bincount((v >> 1) & 7)[:5])
 print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}); RZ histogram {np.bincount(rz)[:6]}; "
       f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
       f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
 clk, wall, iters, samp = spp[::16, 1::32][m].astype(np.float64), spp[::16, 2::32][m].astype(np.float64), spp[::16, 3::32][m].astype(np.float64), spp[::16, 4::32][m].astype(np.float64)
 ok = wall > 0
+for flag, name in ((1, "staged"), (0, "not staged")):
+    sel = ok & (staged == flag)
+    if sel.any():
+        print(f"  {name}: {int(sel.sum())} tiles, march wall time per tile us: percentiles 10/50/90/100 {np.round(np.percentile(wall[sel] / 100, [10, 50, 90, 100]), 1)}, sum {wall[sel].sum() / 100 / 1e3:.1f} ms; phases mean {phases[sel].mean():.0f}")
 print(f"staged loop per tile: {clk[ok].mean():.0f} shader-clock ticks in {wall[ok].mean() / 100:.1f} us -> {np.median(clk[ok] / wall[ok]) * 100 / 1e3:.3f} GHz (median over tiles); wavefront 0: {iters[ok].sum():.0f} iterations for {samp[ok].sum():.0f} lane-0 samples ({iters[ok].sum() / max(samp[ok].sum(), 1):.3f} iterations per sample of lane 3)")
 for _ in range(150):
     r.renderAsync()

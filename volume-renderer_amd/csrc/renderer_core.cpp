@@ -618,7 +618,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    L.tri_slab = force_generic == 6 ? 1 : 0;                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
+    L.tri_slab = force_generic == 6 ? 1 : (force_generic == 7 ? 2 : 0);                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -761,6 +761,13 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
     uint64_t key = tileScheduleKey(P, launch_local_rows(P), false);
     auto mix = [&](uint64_t v) { key ^= v + 0x9E3779B97F4A7C15ull + (key << 6) + (key >> 2); };
     mix((uint64_t)(viewAxisAlignment(P) * 25.0));
+    if (L.filter == 1) {
+        // the staged trilinear kernel's time follows how many tiles' brick layers fit its ring, i.e. HOW the view is oblique
+        // (orbit poses of one alignment bucket: 1.2 ... 2.5 ms on a 1024^3 u8 volume): both direction ratios, in eighths
+        double r1, r2;
+        viewAxisRatios(P, r1, r2);
+        mix((uint64_t)(r1 * 8.0) << 8 | (uint64_t)(r2 * 8.0));
+    }
     mix((uint64_t)(std::log2((double)std::max(tile_active_, 1u)) * 3.0));
     uint32_t abits; std::memcpy(&abits, &P.alpha_scale, 4);
     mix(abits); mix((uint64_t)(uint32_t)P.min_val << 32 | (uint32_t)P.max_val);
@@ -960,7 +967,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // layers then fit the ring three deep (cfg3 default pose: every tile staged, 1.36 vs 1.93 ms); an oblique view's
     // layers are ~1.5x as large, most tiles would march on global taps (4.1 vs 3.2 ms), so it keeps the batched kernel.
     // Volumes the batched kernel cannot take (beyond 32-bit offsets, or with a transfer function) always go staged.
-    if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L) && (aligned || !tri_path_candidate(P, L))) L.tri_slab = 1;
+    // 8-bit volumes: a slot is 80 B, nearly every oblique tile fits as well (orbit poses 1.2-1.6 ms against 2.1 batched).
+    if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L) && (aligned || L.bytes_per_voxel == 1 || !tri_path_candidate(P, L))) L.tri_slab = 1;
     // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is
     // a single under-filled round of long serial rays -- few active tiles, scaled by how long the rays are (1045 samples
     // on the configuration the 256 / 1024 were measured on; a 256^3 volume's 262-sample rays want 4x fewer tiles)

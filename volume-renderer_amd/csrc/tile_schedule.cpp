@@ -46,6 +46,27 @@ int globalRow(const FrameParams &P, int ly)
 
 }  // namespace
 
+static void centralRayVoxelUnits(const FrameParams &P, double m[3])
+{
+    const float *c = P.cam;
+    const bool swz = P.view_top == 1 || P.view_bottom == 1;          // box y / z carry voxel z / y in the rotated views
+    const double vdim[3] = {(double)P.nx, swz ? (double)P.nz : (double)P.ny, swz ? (double)P.ny : (double)P.nz};
+    for (int r = 0; r < 3; r++) {
+        const double ext = (double)P.ext[r] > 0.0 ? (double)P.ext[r] : 1.0;
+        m[r] = -(double)c[8 + r] * (double)c[20] * vdim[r] / ext;
+    }
+}
+
+void viewAxisRatios(const FrameParams &P, double &mid_over_max, double &min_over_max)
+{
+    double m[3];
+    centralRayVoxelUnits(P, m);
+    double v[3] = {std::fabs(m[0]), std::fabs(m[1]), std::fabs(m[2])};
+    std::sort(v, v + 3);
+    mid_over_max = v[2] > 0.0 ? v[1] / v[2] : 0.0;
+    min_over_max = v[2] > 0.0 ? v[0] / v[2] : 0.0;
+}
+
 double viewAxisAlignment(const FrameParams &P)
 {
     const float *c = P.cam;

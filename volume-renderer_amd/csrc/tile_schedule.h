@@ -26,6 +26,8 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
 // how close the view is to a volume axis: |largest component| of the central ray's direction in voxel units, 1 = along
 // an axis, 0.58 = along the space diagonal.  Launch heuristics only (RendererCore::prepareLaunch).
 double viewAxisAlignment(const FrameParams &P);
+// the central ray's two smaller |components| (voxel units) over its largest: 0, 0 = along an axis; 1, 1 = a body diagonal
+void viewAxisRatios(const FrameParams &P, double &mid_over_max, double &min_over_max);
 
 // cheap fingerprint of everything the schedule depends on; with_camera = false: of everything
 // that decides WHICH tiles exist (image, shard, volume box) -- the camera only decides their order

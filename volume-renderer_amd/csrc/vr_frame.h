@@ -85,7 +85,7 @@ struct LaunchConfig {
     uint32_t packed12_bytes;
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip; host: aligned views, vr_set_kernel_variant 6 forces it)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip; host: aligned views, vr_set_kernel_variant 6 forces it); 2 = that kernel with staging switched off (variant 7)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

@@ -1777,7 +1777,7 @@ bool tri_slab_candidate(const FrameParams &P, const LaunchConfig &L)
     if (P.tf_len > 256) return false;
     const uint64_t bricks = (uint64_t)P.bnx * (uint64_t)P.bny * (uint64_t)P.bnz;
     if (bricks >= (1ull << 32) || (uint64_t)P.bnx * (uint64_t)P.bny >= (1ull << 24)) return false;
-    return P.nx + P.ny + P.nz <= (L.bytes_per_voxel == 1 ? 6144 : 3072);
+    return P.nx <= 32768 && P.ny <= 32768 && P.nz <= 32768;           // 16-bit brick indices in the load plan; plan and tables cover a tile's own range only
 }
 
 static bool tri_slab_selected(const FrameParams &P, const LaunchConfig &L)

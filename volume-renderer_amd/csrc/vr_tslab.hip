@@ -54,8 +54,8 @@ template <typename VoxelT> constexpr int ts_lds_bytes() { return VR_X_LDSKB * 10
 template <typename VoxelT> constexpr int ts_lds_bytes() { return 80 * 1024 - 512; }
 #endif
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
-constexpr int TS_MAX_PIECES = 3;                          // 1-KiB DMA pieces per wavefront per layer
-constexpr int TS_MAX_LAYERS = 1536;                       // brick layers along the major axis the plan can hold
+constexpr int TS_MAX_PIECES = 4;                          // 1-KiB DMA pieces per wavefront per layer
+constexpr int TS_FB_BATCH = 4;                            // samples whose taps a tile that is not staged requests together
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
 template <typename VoxelT, int MODE>
@@ -77,13 +77,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
                                                                        const float4 *__restrict__ tf,
                                                                        float4 *__restrict__ fb,
                                                                        uint32_t *__restrict__ spp,
-                                                                       const uint32_t *__restrict__ tile_table)
+                                                                       const uint32_t *__restrict__ tile_table,
+                                                                       const int no_stage)
 {
     using C = TslabCfg<VoxelT, MODE>;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
     __shared__ float corner[5][4];              // rows 0..3: G of the corner rays, row 4: E (voxel coordinates)
-    __shared__ int red[8];                      // 0: min first progress, 1: max last progress, 2: max prefix length, 3 / 4: max rectangle extents
+    __shared__ int red[12];                     // 0: min first progress, 1: max last progress, 2: max prefix length, 3 / 4: max rectangle extents,
+                                                // 5: clamp flag, 6..9: min / max brick index of the live rectangles along a and b
     static_assert(sizeof(corner) + sizeof(red) <= C::MISC_BYTES, "LDS budget");
 
     const uint32_t t = tile_table[blockIdx.x];
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         corner[cidx][0] = gx - ex; corner[cidx][1] = gy - ey; corner[cidx][2] = gz - ez;
         if (cidx == 0) { corner[4][0] = ex; corner[4][1] = ey; corner[4][2] = ez; }
     }
-    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; }
+    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; red[6] = 0x7fffffff; red[7] = -1; red[8] = 0x7fffffff; red[9] = -1; }
     __syncthreads();
     float G[4][3], E[3];
 #pragma unroll
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         ax_m = (g0 >= g1 && g0 >= g2) ? 0 : (g1 >= g2 ? 1 : 2);
     }
     const int ax_a = ax_m == 0 ? 1 : 0, ax_b = ax_m == 2 ? 1 : 2;
-    bool stage = true;
+    bool stage = no_stage == 0;                                          // (vr_set_kernel_variant 7: every tile on global taps, the cross-check of that path)
     int sgn = 1;
     {
         bool pos = true, neg = true;
@@ -304,7 +306,6 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const int nbr0 = P.bnx, nbr1 = P.bny, nbr2 = P.bnz;                // bricks per voxel axis
     const int nbr_m = sel3(ax_m, nbr0, nbr1, nbr2), nbr_a = sel3(ax_a, nbr0, nbr1, nbr2), nbr_b = sel3(ax_b, nbr0, nbr1, nbr2);
     const int ndim_m = sel3(ax_m, P.nx, P.ny, P.nz);
-    if (nbr_m > TS_MAX_LAYERS) stage = false;
     // layer (along m) of the cell a position's taps start in: floor(max(f_m - 0.5, 0)) >> 2
     auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> 2; };
     {
@@ -335,19 +336,18 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const float nmax = fmaxf(fmaxf(P.fdim[0], P.fdim[1]), P.fdim[2]);
     const float emax = fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fabsf(E[2]));
     const float delta = TS_MARGIN + (float)kmax * 1.2e-7f * nmax + emax * 2.4e-7f;
-    // LDS carve-up behind the ring: the plan (8 bytes per layer), then the torus tables -- BYTE offsets, 16-bit for the two
-    // minor axes (a slot row / a layer is < 64 KiB), 32-bit for the major axis (ring base + layer slot + plane)
+    // LDS carve-up: [plan | torus tables | ring].  Plan and tables cover only what this tile can touch -- the layers
+    // between one before its first and three past its last (the prefetch distance), and the voxel indices of those
+    // layers' rectangles -- so a 2048^3 volume costs the ring ~1 KiB instead of 20 and oblique footprints get the rest.
+    // The tables hold BYTE offsets, 16-bit for the two minor axes (a slot row / a layer is < 64 KiB), 32-bit for the
+    // major axis (ring base + layer slot + plane); they are addressed through virtual bases (real base - first index).
     const int ndim_a = sel3(ax_a, P.nx, P.ny, P.nz), ndim_b = sel3(ax_b, P.nx, P.ny, P.nz);
-    const int plan_bytes = (nbr_m * 8 + 15) & ~15;
-    const int taba_bytes = ((ndim_a + 1) * 2 + 3) & ~3, tabb_bytes = ((ndim_b + 1) * 2 + 3) & ~3, tabm_bytes = (ndim_m + 1) * 4;
-    const int tail_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 15) & ~15;
-    if (tail_bytes > C::REGION / 2) stage = false;
-    uint8_t *tail = ring + (stage ? C::REGION - tail_bytes : 0);
-    uint2 *plan = reinterpret_cast<uint2 *>(tail);
-    uint16_t *tab_a = reinterpret_cast<uint16_t *>(tail + plan_bytes), *tab_b = reinterpret_cast<uint16_t *>(tail + plan_bytes + taba_bytes);
-    uint32_t *tab_m = reinterpret_cast<uint32_t *>(tail + plan_bytes + taba_bytes + tabb_bytes);
+    const int Llo = max(sgn > 0 ? c_first - 1 : -(c_last + 3), 0), Lhi = min(sgn > 0 ? c_last + 3 : -(c_first - 1), nbr_m - 1);
+    const int n_plan = max(Lhi - Llo + 1, 0);
+    const int plan_bytes = (n_plan * 8 + 15) & ~15;
+    uint2 *plan = reinterpret_cast<uint2 *>(ring) - Llo;                 // plan[L] for Llo <= L <= Lhi
     if (stage && any_prefix) {
-        for (int L = (int)threadIdx.x; L < nbr_m; L += TS_THREADS) {
+        for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
             const float c_lo = (float)(4 * L) - 0.5f - delta, c_hi = (float)(4 * L) + 4.5f + delta;
             float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
 #pragma unroll
@@ -367,17 +367,31 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
             const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
             plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
-            const int cL = sgn * L;
-            if (cL >= c_first - 1 && cL <= c_last + 3) {                 // layers some phase reads (L_p and L_p + 1) or prefetches
-                atomicMax(&red[3], dda);
-                atomicMax(&red[4], ddb);
-                if (amin - delta < 1.0f || bmin - delta < 1.0f) atomicOr(&red[5], 1);   // some ray comes within a voxel of a low face
-            }
+            atomicMax(&red[3], dda);                                     // every planned layer is one some phase reads or prefetches
+            atomicMax(&red[4], ddb);
+            atomicMin(&red[6], lo_a); atomicMax(&red[7], hi_a);
+            atomicMin(&red[8], lo_b); atomicMax(&red[9], hi_b);
+            if (amin - delta < 1.0f || bmin - delta < 1.0f) atomicOr(&red[5], 1);   // some ray comes within a voxel of a low face
         }
     }
     __syncthreads();
     const int RA = uniform_i(red[3]) + 1, RB = uniform_i(red[4]) + 1;
-    const int slots_avail = (C::REGION - tail_bytes) / C::SLOT;
+    // voxel index ranges of the tables: [first, last] per role, + 1 entry for the "index + 1" look-ups (at the high face
+    // it repeats the last voxel: the + 1 tap of the last cell is the clamped one)
+    const int ia_lo = 4 * clampi(uniform_i(red[6]), 0, nbr_a), ia_hi = min(4 * clampi(uniform_i(red[7]), -1, nbr_a) + 4, ndim_a);   // (nothing planned: empty)
+    const int ib_lo = 4 * clampi(uniform_i(red[8]), 0, nbr_b), ib_hi = min(4 * clampi(uniform_i(red[9]), -1, nbr_b) + 4, ndim_b);
+    const int im_lo = 4 * Llo, im_hi = min(4 * Lhi + 4, ndim_m);
+    const int na_e = max(ia_hi - ia_lo + 1, 0), nb_e = max(ib_hi - ib_lo + 1, 0), nm_e = max(im_hi - im_lo + 1, 0);
+    const int taba_bytes = (na_e * 2 + 3) & ~3, tabb_bytes = (nb_e * 2 + 3) & ~3, tabm_bytes = nm_e * 4;
+    const int head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 15) & ~15;
+    if (head_bytes > C::REGION / 2) stage = false;
+    uint16_t *tab_a = reinterpret_cast<uint16_t *>(ring + plan_bytes), *tab_b = reinterpret_cast<uint16_t *>(ring + plan_bytes + taba_bytes);
+    uint32_t *tab_m = reinterpret_cast<uint32_t *>(ring + plan_bytes + taba_bytes + tabb_bytes);
+    uint8_t *const slots = ring + (stage ? head_bytes : 0);             // the torus of brick slots
+    const int slots_avail = (C::REGION - head_bytes) / C::SLOT;
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
+    const unsigned st_reason = !stage ? 1u : (RA * RB > C::LAYER_SLOTS_MAX ? 2u : (RA * RB * 3 > slots_avail ? 3u : (RA * RB * C::SLOT > 65535 ? 4u : 0u)));
+#endif
     if (RA * RB > C::LAYER_SLOTS_MAX || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * C::SLOT > 65535) stage = false;
     const int RZ = stage ? min(slots_avail / (RA * RB), 4) : 1;
     const int LA = RZ - 2;                                               // phases of prefetch distance: 1 or 2
@@ -393,7 +407,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     for (int q = 0; q < TS_MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
     if (stage && any_prefix) {
         // torus position of every layer's rectangle origin (second word of the plan entries)
-        for (int L = (int)threadIdx.x; L < nbr_m; L += TS_THREADS) {
+        for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
             uint2 e = plan[L];
             e.y |= ((e.x & 0xffffu) % (uint32_t)RA) << 16 | ((e.x >> 16) % (uint32_t)RB) << 24;
             plan[L] = e;
@@ -401,20 +415,20 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         // torus tables: N + 1 entries per axis (the last one repeats voxel N - 1: the + 1 tap of the last cell is the
         // clamped one): byte offset of the slot of brick (i >> 2) mod R + of the position inside the 5x4x4 apron brick;
         // the major axis' entries include the ring's LDS base, so a tap address is the plain sum of three entries
-        const int na = ndim_a + ndim_b + ndim_m + 3;
+        const int na = na_e + nb_e + nm_e;
         for (int e = (int)threadIdx.x; e < na; e += TS_THREADS) {
             int role, ii;                                                // role 0 / 1 / 2 = axis a / b / m
-            if (e < ndim_a + 1) { role = 0; ii = min(e, ndim_a - 1); }
-            else if (e < ndim_a + ndim_b + 2) { role = 1; ii = min(e - ndim_a - 1, ndim_b - 1); }
-            else { role = 2; ii = min(e - ndim_a - ndim_b - 2, ndim_m - 1); }
+            if (e < na_e) { role = 0; ii = min(ia_lo + e, ndim_a - 1); }
+            else if (e < na_e + nb_e) { role = 1; ii = min(ib_lo + e - na_e, ndim_b - 1); }
+            else { role = 2; ii = min(im_lo + e - na_e - nb_e, ndim_m - 1); }
             const int axis = role == 0 ? ax_a : (role == 1 ? ax_b : ax_m);
             const int R = role == 0 ? RA : (role == 1 ? RB : RZ);
             const uint32_t stride = role == 0 ? (uint32_t)C::SLOT : (role == 1 ? (uint32_t)(RA * C::SLOT) : (uint32_t)(RA * RB * C::SLOT));
             const uint32_t in = (uint32_t)(ii & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u)) * (uint32_t)sizeof(VoxelT);
             const uint32_t off = (uint32_t)((ii >> 2) % R) * stride + in;
             if (role == 0) tab_a[e] = (uint16_t)off;
-            else if (role == 1) tab_b[e - ndim_a - 1] = (uint16_t)off;
-            else tab_m[e - ndim_a - ndim_b - 2] = off + lds_offset_of(ring);
+            else if (role == 1) tab_b[e - na_e] = (uint16_t)off;
+            else tab_m[e - na_e - nb_e] = off + lds_offset_of(slots);
         }
 #pragma unroll
         for (int q = 0; q < TS_MAX_PIECES; q++) {
@@ -427,12 +441,12 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         }
     }
     __syncthreads();
-    const uint32_t ring_base = lds_offset_of(ring);
+    const uint32_t ring_base = lds_offset_of(slots);
 
     // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ; returns the number of DMA
     // instructions this wavefront issued
     auto issue_layer = [&](int L) -> int {
-        if (L < 0 || L >= nbr_m) return 0;
+        if (L < Llo || L > Lhi) return 0;
         const uint2 e = plan[L];
         const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
         const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
@@ -478,7 +492,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
         float wx = 0.0f, wy = 0.0f, wz = 0.0f;
         int lay = -0x7fffffff;
-        const uint32_t tab_a_b = lds_offset_of(tab_a), tab_b_b = lds_offset_of(tab_b), tab_m_b = lds_offset_of(tab_m);
+        // virtual table bases: real base - first index (unsigned wrap-around is fine, the sum is what is used)
+        const uint32_t tab_a_b = lds_offset_of(tab_a) - 2u * (uint32_t)ia_lo, tab_b_b = lds_offset_of(tab_b) - 2u * (uint32_t)ib_lo, tab_m_b = lds_offset_of(tab_m) - 4u * (uint32_t)im_lo;
         // byte offset of voxel index `idx` (and of idx + 1) along voxel axis AX, from the table of the role AX plays
         auto look = [&](auto ax_tag, int idx, uint32_t &o0, uint32_t &o1) {
             constexpr int AX = decltype(ax_tag)::value;
@@ -608,8 +623,61 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         else if (ax_m == 1) staged_march(std::integral_constant<int, 1>{});
         else staged_march(std::integral_constant<int, 2>{});
     } else if (any_prefix) {
-        // ---- not staged: the prefix on global taps, sample by sample (positions inside the safe prefix: no bounds tests)
-        while (rem > 0) {
+        // ---- not staged: the prefix on global taps (positions inside the safe prefix: no bounds tests).  A tile that is
+        // not staged is usually one of a few in a frame of staged ones, and its eight wavefronts share ONE compute unit's
+        // vector L1 (4 cycles per cache line per gather instruction): what it costs the frame is its own duration, i.e.
+        // gather instructions per sample x ~1000 samples.  So it gathers from the APRON copy like the batched kernel
+        // (vr_kernels.hip: raymarch_tri_kernel) -- the x1 tap is the x0 tap's next element: four pair loads per sample
+        // instead of eight single taps -- through per-axis offset tables built in the LDS the ring does not need (64-bit
+        // along z: volumes beyond 4 GiB), with the staged path's clamp-free index rule, and the taps of TS_FB_BATCH
+        // consecutive samples are requested together (16 independent loads per lane) before the first is composited.
+        // Samples behind the one that ends the ray were fetched for nothing (valid addresses: the safe prefix).
+        const int gxy_bytes = ((P.nx + P.ny + 1) * 4 + 7) & ~7;
+        const bool fb_tables = gxy_bytes + (P.nz + 1) * 8 <= C::REGION;   // (an axis too long for that: the loop below)
+        uint32_t *gx = reinterpret_cast<uint32_t *>(ring), *gy = gx + P.nx;
+        uint64_t *gz = reinterpret_cast<uint64_t *>(ring + gxy_bytes);
+        if (fb_tables) {
+            const uint32_t sz = (uint32_t)sizeof(VoxelT), bnx = (uint32_t)P.bnx;
+            const uint64_t bxy = (uint64_t)P.bnx * (uint64_t)P.bny;
+            for (int e = (int)threadIdx.x; e < P.nx + P.ny + P.nz + 2; e += TS_THREADS) {
+                if (e < P.nx) { const uint32_t ii = (uint32_t)e; gx[e] = ((ii >> 2) * APRON_BRICK_VOXELS + (ii & 3u)) * sz; }
+                else if (e < P.nx + P.ny + 1) { const uint32_t jj = (uint32_t)min(e - P.nx, P.ny - 1); gy[e - P.nx] = ((jj >> 2) * bnx * APRON_BRICK_VOXELS + (jj & 3u) * 5u) * sz; }
+                else { const uint64_t kk = (uint64_t)min(e - P.nx - P.ny - 1, P.nz - 1); gz[e - P.nx - P.ny - 1] = ((kk >> 2) * bxy * APRON_BRICK_VOXELS + (kk & 3u) * 20u) * sz; }
+            }
+            __syncthreads();
+            auto pair_word = [&](uint64_t off) -> uint32_t {           // (x0, x1): one load, aligned to the voxel size only
+                if (sizeof(VoxelT) == 2) { uint32_t w; __builtin_memcpy(&w, src + off, 4); return w; }
+                uint16_t w; __builtin_memcpy(&w, src + off, 2); return (uint32_t)w;
+            };
+            while (rem >= TS_FB_BATCH && !done) {
+                uint32_t pw[TS_FB_BATCH][4];
+                float wt[TS_FB_BATCH][3];
+#pragma unroll
+                for (int u = 0; u < TS_FB_BATCH; u++) {
+                    float fx, fy, fz;
+                    scaled_here(fx, fy, fz);
+                    const float ux = fmaxf(fx - 0.5f, 0.0f), uy = fmaxf(fy - 0.5f, 0.0f), uz = fmaxf(fz - 0.5f, 0.0f);
+                    const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;   // == floor: u >= 0; i0 <= n - 1 inside the safe prefix
+                    wt[u][0] = __builtin_amdgcn_fractf(ux); wt[u][1] = __builtin_amdgcn_fractf(uy); wt[u][2] = __builtin_amdgcn_fractf(uz);
+                    const uint32_t xy0 = gx[i0] + gy[j0], xy1 = gx[i0] + gy[j0 + 1];
+                    const uint64_t z0 = gz[k0], z1 = gz[k0 + 1];
+                    pw[u][0] = pair_word(z0 + xy0); pw[u][1] = pair_word(z0 + xy1); pw[u][2] = pair_word(z1 + xy0); pw[u][3] = pair_word(z1 + xy1);
+                    advance();
+                }
+#pragma unroll
+                for (int u = 0; u < TS_FB_BATCH; u++) {
+                    if (da >= 0.95f) { done = true; break; }
+                    constexpr uint32_t VM = sizeof(VoxelT) == 1 ? 0xffu : 0xffffu;
+                    constexpr int VS = sizeof(VoxelT) == 1 ? 8 : 16;
+                    const uint32_t tv[8] = {pw[u][0] & VM, pw[u][0] >> VS, pw[u][1] & VM, pw[u][1] >> VS, pw[u][2] & VM, pw[u][2] >> VS, pw[u][3] & VM, pw[u][3] >> VS};
+                    float c, cg = 0.0f, cb = 0.0f, a;
+                    shade(tv, wt[u][0], wt[u][1], wt[u][2], c, cg, cb, a);
+                    accumulate(c, cg, cb, a);
+                    i++; rem--;
+                }
+            }
+        }
+        while (rem > 0 && !done) {
             if (da >= 0.95f) { done = true; break; }
             float fx, fy, fz, ax, ay, az, c, cg = 0.0f, cb = 0.0f, a;
             uint32_t tv[8];
@@ -638,7 +706,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
 #if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)      // per-tile statistics instead of the fetch count of the tile's first pixel
-    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | ((unsigned)RZ << 4) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
+    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | (st_reason << 1) | ((unsigned)RZ << 4) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
     // shader-clock ticks and 100 MHz wall ticks of the staged loop (threads 1, 2), iterations and samples of wavefront 0 (threads 3, 4)
     if (spp && threadIdx.x == 1) { spp[pix] = (uint32_t)(clock64() - st_clk0); return; }
     if (spp && threadIdx.x == 2) { spp[pix] = (uint32_t)(wall_clock64() - st_wall0); return; }
@@ -654,7 +722,7 @@ static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, cons
                                uint32_t *spp, hipStream_t st)
 {
     hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE>), dim3(L.tile_table_blocks), dim3(TS_THREADS), 0, st, P,
-                       (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table);
+                       (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table, L.tri_slab == 2 ? 1 : 0);
     return hipGetLastError();
 }
 
