@@ -33,7 +33,9 @@ print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} (
       f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
       f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
 clk, wall, iters, samp = spp[::16, 1::32][m].astype(np.float64), spp[::16, 2::32][m].astype(np.float64), spp[::16, 3::32][m].astype(np.float64), spp[::16, 4::32][m].astype(np.float64)
+setup = spp[::16, 5::32][m].astype(np.float64)
 ok = wall > 0
+print(f"set-up before the march (ray, checked head, load plan, tables): mean {setup[ok].mean():.0f} ticks = {100 * setup[ok].sum() / (setup[ok].sum() + clk[ok].sum()):.1f} % of the tiles' time")
 for flag, name in ((1, "staged"), (0, "not staged")):
     sel = ok & (staged == flag)
     if sel.any():

@@ -63,6 +63,20 @@ __device__ __forceinline__ float wave_max_f(float v)
     v = fmaxf(v, dpp_f<0x140>(v));
     return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
+// integer wave reductions (every lane of the wavefront must execute them: inactive lanes would leave stale registers behind
+// the read-lanes).  Same-address LDS atomics cost ~18 cycles per LANE on gfx950 (measured: 7 atomics by 256 threads = 3 %
+// of a 480-us tile), so reductions go through these first and one lane per wavefront does the atomic.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
 template <typename T> __device__ __forceinline__ T sel3(int ax, T v0, T v1, T v2) { return ax == 0 ? v0 : (ax == 1 ? v1 : v2); }
 
 }  // namespace vr

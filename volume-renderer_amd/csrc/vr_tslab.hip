@@ -54,7 +54,6 @@ template <typename VoxelT> constexpr int ts_lds_bytes() { return VR_X_LDSKB * 10
 template <typename VoxelT> constexpr int ts_lds_bytes() { return 80 * 1024 - 512; }
 #endif
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
-constexpr int TS_MAX_PIECES = 4;                          // 1-KiB DMA pieces per wavefront per layer
 constexpr int TS_FB_BATCH = 4;                            // samples whose taps a tile that is not staged requests together
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
@@ -67,7 +66,9 @@ struct TslabCfg {
     // one region carved per tile into [ring | plan | torus tables]: the tables' size follows the volume's dimensions
     // (2 bytes per voxel index of the two minor axes, 4 per index of the major axis)
     static constexpr int REGION = (ts_lds_bytes<VoxelT>() - LUT_BYTES - MISC_BYTES) / 16 * 16;
-    static constexpr int LAYER_SLOTS_MAX = TS_MAX_PIECES * TS_NW * 64 / CH;
+    // 1-KiB DMA pieces per wavefront per layer: what three layers of the ring can hold (u16: 153 slots of 160 B, u8: 409 of 80 B)
+    static constexpr int MAX_PIECES = sizeof(VoxelT) == 1 ? 4 : 3;
+    static constexpr int LAYER_SLOTS_MAX = MAX_PIECES * TS_NW * 64 / CH;
 };
 
 template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
 
     const uint32_t t = tile_table[blockIdx.x];
     if (t == 0xffffffffu) return;                                       // padding block
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
+    const uint64_t st_entry = clock64();
+#endif
     const unsigned tx = t & 0xffffu, ty = t >> 16;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const int lx = (int)(tx * kFastTileW + (wave & 3u) * 8u + (lane & 7u));
@@ -310,6 +314,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> 2; };
     {
         // first / last layer of this ray's prefix in progress coordinates (sgn * layer), prefix length: workgroup extremes
+        // (wavefront reductions first: one lane per wavefront touches the LDS words)
+        int r_first = 0x7fffffff, r_last = -0x7fffffff, r_len = 0;
         if (rem > 0) {
             float fx, fy, fz;
             scaled_here(fx, fy, fz);
@@ -318,10 +324,12 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             const float kk = (float)(rem - 1);
             voxel_float((POW2 ? Qx / Sx : qx) + kk * dsx, (POW2 ? Qy / Sy : qy) + kk * dsy, (POW2 ? Qz / Sz : qz) + kk * dsz, lx2, ly2, lz2);
             const int l_last = layer_of(sel3(ax_m, lx2, ly2, lz2));
-            atomicMin(&red[0], sgn * l_first);
-            atomicMax(&red[1], sgn * l_last + 1);                        // + 1: the closed form may sit one layer short
-            atomicMax(&red[2], rem);
+            r_first = sgn * l_first;
+            r_last = sgn * l_last + 1;                                   // + 1: the closed form may sit one layer short
+            r_len = rem;
         }
+        r_first = wave_min_i(r_first); r_last = wave_max_i(r_last); r_len = wave_max_i(r_len);
+        if (lane == 0) { atomicMin(&red[0], r_first); atomicMax(&red[1], r_last); atomicMax(&red[2], r_len); }
     }
     __syncthreads();
     const int c_first = uniform_i(red[0]), kmax = uniform_i(red[2]);
@@ -347,6 +355,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const int plan_bytes = (n_plan * 8 + 15) & ~15;
     uint2 *plan = reinterpret_cast<uint2 *>(ring) - Llo;                 // plan[L] for Llo <= L <= Lhi
     if (stage && any_prefix) {
+        int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1, m_low = 0;
         for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
             const float c_lo = (float)(4 * L) - 0.5f - delta, c_hi = (float)(4 * L) + 4.5f + delta;
             float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
@@ -367,11 +376,15 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
             const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
             plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
-            atomicMax(&red[3], dda);                                     // every planned layer is one some phase reads or prefetches
-            atomicMax(&red[4], ddb);
-            atomicMin(&red[6], lo_a); atomicMax(&red[7], hi_a);
-            atomicMin(&red[8], lo_b); atomicMax(&red[9], hi_b);
-            if (amin - delta < 1.0f || bmin - delta < 1.0f) atomicOr(&red[5], 1);   // some ray comes within a voxel of a low face
+            m_dda = max(m_dda, dda); m_ddb = max(m_ddb, ddb);            // every planned layer is one some phase reads or prefetches
+            m_loa = min(m_loa, lo_a); m_hia = max(m_hia, hi_a); m_lob = min(m_lob, lo_b); m_hib = max(m_hib, hi_b);
+            if (amin - delta < 1.0f || bmin - delta < 1.0f) m_low = 1;   // some ray comes within a voxel of a low face
+        }
+        m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low);
+        m_loa = wave_min_i(m_loa); m_hia = wave_max_i(m_hia); m_lob = wave_min_i(m_lob); m_hib = wave_max_i(m_hib);
+        if (lane == 0) {
+            atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low);
+            atomicMin(&red[6], m_loa); atomicMax(&red[7], m_hia); atomicMin(&red[8], m_lob); atomicMax(&red[9], m_hib);
         }
     }
     __syncthreads();
@@ -383,7 +396,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const int im_lo = 4 * Llo, im_hi = min(4 * Lhi + 4, ndim_m);
     const int na_e = max(ia_hi - ia_lo + 1, 0), nb_e = max(ib_hi - ib_lo + 1, 0), nm_e = max(im_hi - im_lo + 1, 0);
     const int taba_bytes = (na_e * 2 + 3) & ~3, tabb_bytes = (nb_e * 2 + 3) & ~3, tabm_bytes = nm_e * 4;
-    const int head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 15) & ~15;
+    // (the ring starts on a 256-byte boundary: the 1-KiB DMA pieces then land on whole LDS rows, 1 % on the 1024^3 workload)
+    const int head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 255) & ~255;
     if (head_bytes > C::REGION / 2) stage = false;
     uint16_t *tab_a = reinterpret_cast<uint16_t *>(ring + plan_bytes), *tab_b = reinterpret_cast<uint16_t *>(ring + plan_bytes + taba_bytes);
     uint32_t *tab_m = reinterpret_cast<uint32_t *>(ring + plan_bytes + taba_bytes + tabb_bytes);
@@ -401,10 +415,10 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const uint32_t sA = sel3(ax_a, str0, str1, str2), sB = sel3(ax_b, str0, str1, str2), sM = sel3(ax_m, str0, str1, str2);
     // per-lane loader constants of piece q: torus coordinates (ta, tb) of the slot this lane's 16-byte chunk belongs to,
     // the chunk's index inside the slot, and whether the slot exists
-    int ld_ta[TS_MAX_PIECES], ld_tb[TS_MAX_PIECES], ld_part[TS_MAX_PIECES];
-    bool ld_ok[TS_MAX_PIECES];
+    int ld_ta[C::MAX_PIECES], ld_tb[C::MAX_PIECES], ld_part[C::MAX_PIECES];
+    bool ld_ok[C::MAX_PIECES];
 #pragma unroll
-    for (int q = 0; q < TS_MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
+    for (int q = 0; q < C::MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
     if (stage && any_prefix) {
         // torus position of every layer's rectangle origin (second word of the plan entries)
         for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             else tab_m[e - na_e - nb_e] = off + lds_offset_of(slots);
         }
 #pragma unroll
-        for (int q = 0; q < TS_MAX_PIECES; q++) {
+        for (int q = 0; q < C::MAX_PIECES; q++) {
             const int c = (q * TS_NW + (int)wave) * 64 + (int)lane;
             const int slot = c / C::CH;
             ld_part[q] = c - slot * C::CH;
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
         const uint32_t layer_idx = (uint32_t)L * sM;
         int n = 0;
 #pragma unroll
-        for (int q = 0; q < TS_MAX_PIECES; q++) {
+        for (int q = 0; q < C::MAX_PIECES; q++) {
             if (q >= pieces) break;
             int oa = ld_ta[q] - la, ob = ld_tb[q] - lb;
             if (oa < 0) oa += RA;
@@ -712,6 +726,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     if (spp && threadIdx.x == 2) { spp[pix] = (uint32_t)(wall_clock64() - st_wall0); return; }
     if (spp && threadIdx.x == 3) { spp[pix] = st_iters; return; }
     if (spp && threadIdx.x == 4) { spp[pix] = st_samples; return; }
+    if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; }   // set-up: ray, head, plan, tables
 #endif
     if (spp) spp[pix] = (uint32_t)i;
 }
