@@ -909,10 +909,12 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         int b = 0;
         bool fin = nb == 0;
         if (!fin) issue(va, wa, pa, ra);
-        for (;;) {
-            if (__syncthreads_and(fin ? 1 : 0)) break;
+        for (unsigned it = 0;; it++) {
+            // lockstep: one plain barrier per 16 samples, every 4th doubles as the vote "all rays finished" (as in the fast kernel)
+            if ((it & 3u) == 0u) { if (__syncthreads_and(fin ? 1 : 0)) break; }
+            else __syncthreads();
 #pragma unroll 1
-            for (int rep = 0; rep < 4 && !fin; rep++) {      // 16 samples between two lockstep votes
+            for (int rep = 0; rep < 4 && !fin; rep++) {      // 16 samples between two barriers
                 if (b + 1 < nb) issue(vb, wb, pb, rb);
                 if (consume(va, wa, pa, ra)) { done = true; fin = true; break; }
                 if (++b >= nb) { fin = true; break; }
