@@ -728,6 +728,10 @@ def extras(args, r, local, stream, b, W, H):
     if args.pose == "default":
         r.cameraOrient(0.0, -(3.14159265 / 6) / 0.7, (3.14159265 / 4) / 0.7)
         timed("offaxis_deep", steps=10)
+        if args.filter == "nearest":
+            r.setFilter(R.FILTER_TRILINEAR)
+            timed("trilinear_offaxis_deep", steps=10)      # oblique view: the 16-bit volume's brick layers do not fit LDS three deep
+            r.setFilter(R.FILTER_NEAREST)
         r.resetCamera()
     if args.extras:
         # interactive use: the camera moves every frame (GUI orbit), host work included (wall clock)

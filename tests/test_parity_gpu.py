@@ -754,17 +754,18 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
         lo = int(rng.integers(0, vmax // 3)); hi = int(rng.integers(vmax // 2, vmax + 1))
         alpha = float(np.float32(rng.choice([1.0, 0.3, 0.02, 0.0])))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 70))
-        mip = tf = tri = accum = relay = stripes = pipe = tslab = batched = False
+        mip = tf = tri = accum = relay = stripes = pipe = tslab = batched = unstaged = False
         renders = 1
         if extended:
             mode = int(rng.integers(0, 24))
-            mip, tf, tri, accum = mode in (1, 8, 13, 17, 19), mode in (2, 8, 14, 18, 19), mode in (3, 16, 17, 18, 19, 20, 21, 23), mode == 4     # 8: MIP through the transfer function
+            mip, tf, tri, accum = mode in (1, 8, 13, 17, 19), mode in (2, 8, 14, 18, 19), mode in (3, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 23), mode == 4     # 8: MIP through the transfer function
             relay = mode in (5, 6)
             stripes = mode in (7, 15, 21)
             pipe = mode in (9, 10)                # the fast kernel's software-pipelined loop (variant 5) instead of relay / plain loop
             tslab = mode in (16, 17, 21)          # round 3: TRILINEAR on the LDS-staged layer-synchronous kernel (variant 6); 18, 19: with a transfer function
             batched = mode == 20                  # ... and the batched trilinear kernel (variant 2)
-            renders = 5 if mode in (22, 23) else (3 if mode in (12, 13, 14, 15) else 1)    # the measured work model: repeated frames per camera try its candidate kernels (12..15 were the retired NEAREST LDS-staged kernel's modes)
+            unstaged = mode in (12, 13, 14, 15)   # ... with staging switched off (variant 7): the path of tiles whose brick layers do not fit LDS
+            renders = 5 if mode in (22, 23) else 1    # the measured work model: five frames per camera try its candidate kernels
             if rng.random() < 0.2:
                 W, H = int(rng.integers(90, 200)), int(rng.integers(70, 160))
         tf_lut = None
@@ -799,6 +800,8 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                 r.setKernelVariant(5)
             if tslab:
                 r.setKernelVariant(6)
+            if unstaged:
+                r.setKernelVariant(7)
             if batched:
                 r.setKernelVariant(2)
             rows = None
@@ -823,7 +826,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
                                         accum=int(accum), tf_rgba=tf_lut, trunc_grid=quirks & 1)
                 want, _, want_spp = oracle.render(vol, p, want_spp=True)
                 what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} window [{lo},{hi}] alpha {alpha} "
-                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} tslab {tslab} batched {batched} renders {renders} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
+                        f"{W}x{H} mip {mip} tf {tf} tri {tri} accum {accum} relay {relay} tslab {tslab} unstaged {unstaged} batched {batched} renders {renders} stripes {rows} quirks {quirks} pack12 {pack} kernel {r.last_kernel_name}")
                 if rows:                                       # only this shard's rows are rendered
                     mine = np.array([y for y in range(H) if (y // rows[0]) % rows[2] == rows[1]])
                     assert_same(got[mine], want[mine], spp[mine], want_spp[mine], what=what)

@@ -22,3 +22,4 @@ run trilinear_deep --filter trilinear
 run offaxis_deep --pose offaxis
 run headline_without_pack12 --no-pack12
 run shallow_alpha1_ert --alpha 1.0
+run trilinear_offaxis_deep --filter trilinear --pose offaxis
