@@ -280,6 +280,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
     } else if (!fast_tile_of_block(blockIdx.x, tiles_x, tiles_y, chunks_per_row, tx, ty)) {
         return;                                              // padding block
     }
+#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)       // per-tile shader-clock split: set-up | prefix batches | checked tail (tools/fast_stats.py)
+    const uint64_t fs0 = clock64();
+    uint64_t fs1 = fs0, fs2 = fs0;
+#endif
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned mx = lane & 7u, my = lane >> 3;
     const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + mx);
@@ -335,6 +339,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         }
     }
 
+#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
+    fs1 = clock64();
+#endif
     float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f;   // MODE 0/1: r == g == b bit for bit, only drgb is carried
     uint32_t fetches = 0;
     {                                   // every thread runs the (barrier-carrying) batch loop
@@ -657,6 +664,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 }
             }
         }
+#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
+        fs2 = clock64();
+#endif
         // back to box units for the tail (exact: S is a power of two); the step is re-derived
         // from its scaled copy so that only one of the two is live across the batch loop
         float tsx = dsx, tsy = dsy, tsz = dsz;
@@ -676,6 +686,13 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
+#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
+    if (spp && threadIdx.x < 4) {
+        const uint64_t fs3 = clock64();
+        spp[pix] = threadIdx.x == 0 ? 0x80000000u | (uint32_t)(fs1 - fs0) : (threadIdx.x == 1 ? (uint32_t)(fs2 - fs1) : (threadIdx.x == 2 ? (uint32_t)(fs3 - fs2) : fetches));
+        return;
+    }
+#endif
     if (spp) spp[pix] = fetches;
 }
 
