@@ -73,7 +73,6 @@ for ty in range(tiles_y):
         fm_in = np.clip(E[m] + G[:, m] * np.maximum(tmin, 0), 0, N); fm_out = np.clip(E[m] + G[:, m] * tmax, 0, N)
         l_lo, l_hi = int(min(fm_in.min(), fm_out.min())) >> 2, min(int(max(fm_in.max(), fm_out.max())) >> 2, N // 4 - 1)
         delta = 0.0625 + 1100 * 1.2e-7 * N + np.abs(E).max() * 2.4e-7
-        best_rect = best_shear = 0
         ra_r = rb_r = ra_s = rb_s = 0
         # shear: the tile's long edge (corner 0 -> 1); rows along whichever minor axis it advances in faster
         Ls = np.arange(l_lo, l_hi + 1)
@@ -136,5 +135,3 @@ print(f"rectangles: slots percentiles 10/50/90/100 {np.percentile(rect, [10, 50,
 print(f"sheared   : slots percentiles 10/50/90/100 {np.percentile(shear, [10, 50, 90, 100])}; fit {np.mean(shear <= lim):.3f}; best of both fit {np.mean(np.minimum(rect, shear) <= lim):.3f}")
 tight = res[ok, 5] * res[ok, 6]
 print(f"row-tight : slots percentiles 10/50/90/100 {np.percentile(tight, [10, 50, 90, 100])}; fit {np.mean(tight <= lim):.3f}; RA p50/max {np.percentile(res[ok, 5], 50)}/{res[ok, 5].max()}, RB p50/max {np.percentile(res[ok, 6], 50)}/{res[ok, 6].max()}")
-for f in ():
-    print(f"  with {f:.2f} of the tile (a {int(32 * f)}x16 tile would need about): rect fit {np.mean(rect * (f + (1 - f) * 0.4) <= lim):.3f} (crude)")
