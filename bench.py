@@ -599,7 +599,8 @@ def config_extras(device):
       cfg2_shape_ert_window  512x512x452 u16 noise ball (Head CT's shape; the .pvm when VR_DATA_HEAD names it), 1080p,
                              window [1000, 5095] = the reference's +1000 quirk on [0, 4095], alpha 0.05: early ray termination
       cfg4_grey              2048^3 u8 (8 GiB, 64-bit offsets), 3840x2160, grey ramp, window [8, 255], alpha 0.004
-      cfg4_tf_skip           the same through the default alpha-spline transfer function + exact empty-space skipping"""
+      cfg4_tf_skip           the same through the default alpha-spline transfer function + exact empty-space skipping
+    cfg1 / cfg2 / cfg4_grey are also timed with TRILINEAR filtering (<name>_trilinear)."""
     import numpy as np
 
     vra = importlib.import_module("volume-renderer_amd")
@@ -636,6 +637,8 @@ def config_extras(device):
         r.setWindow(0, 255); r.setAlpha(1.0)
         timed(r, "cfg1_shape", 1, 1280, 720, 40)
         out["cfg1_shape"]["data"] = Path(f).name if f else "synthetic sphere 256^3 u8"
+        r.setFilter(R.FILTER_TRILINEAR)                      # the north-star's filter on the same configuration
+        timed(r, "cfg1_shape_trilinear", 1, 1280, 720, 40)
     with renderer(1920, 1080) as r:
         f = os.environ.get("VR_DATA_HEAD")
         if f:
@@ -648,10 +651,16 @@ def config_extras(device):
         r.setAlpha(0.05)
         timed(r, "cfg2_shape_ert_window", 2, 1920, 1080, 40)
         out["cfg2_shape_ert_window"]["data"] = Path(f).name if f else "synthetic noise ball 512x512x452 u16"
+        r.setFilter(R.FILTER_TRILINEAR)
+        timed(r, "cfg2_shape_ert_window_trilinear", 2, 1920, 1080, 40)
     with renderer(3840, 2160) as r:
         r.generateSynthetic(R.SYNTH_NOISE_BALL, (2048, 2048, 2048), 1, 0x9E3779B9)
         r.setWindow(8, 255); r.setAlpha(0.004)
         timed(r, "cfg4_grey", 1, 3840, 2160, 10)
+        r.setFilter(R.FILTER_TRILINEAR)                      # 10 GiB apron copy next to the 8 GiB volume; the LDS-staged kernel (64-bit DMA addresses)
+        timed(r, "cfg4_grey_trilinear", 1, 3840, 2160, 5)
+        out["cfg4_grey_trilinear"]["apron_copy_bytes"] = r.trilinearCopyBytes()
+        r.setFilter(R.FILTER_NEAREST)
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
         r.setSkipEmpty(True)
         timed(r, "cfg4_tf_skip", 1, 3840, 2160, 10)
