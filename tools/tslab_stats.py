@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment (needs a stats build of vr_tslab.hip: make TSLAB_TAG=_st TSLAB_DEFS="-DVR_EXPERIMENTS -DVR_X_STATS", then
 VR_CORE_LIB=.../libvr_core_st.so): per-tile load-plan statistics of the LDS-staged TRILINEAR kernel on the bench workload.
-  tools/tslab_stats.py [default|offaxis] [N] [bytes]"""
+  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -15,7 +15,7 @@ W, H = (1920, 1080) if N <= 1024 else (3840, 2160)
 r = vra.RendererCore(0)
 r.setup((W, H)); r.loadShader("x"); r.setQuirks(0)
 r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
-r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
+r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(float(sys.argv[4]) if len(sys.argv) > 4 else 0.004); r.setFilter(R.FILTER_TRILINEAR)
 if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
 elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
