@@ -2,7 +2,7 @@
 """experiment (needs a stats build of the fast kernel's u16-bricked unit: make K3_TAG=_fs K3_DEFS="-DVR_EXPERIMENTS -DVR_X_FSTATS",
 then VR_CORE_LIB=.../libvr_core_fs.so): per-tile shader-clock split of the headline launch -- set-up (ray, tables, classification
 table) | checked head + prefix batches | checked tail -- for wavefront 0 of every tile.
-  tools/fast_stats.py [default|offaxis] [variant]"""
+  tools/fast_stats.py [default|offaxis] [variant] [alpha_scale]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -13,7 +13,7 @@ pose = sys.argv[1] if len(sys.argv) > 1 else "default"
 r = vra.RendererCore(0)
 r.setup((1920, 1080)); r.loadShader("x"); r.setQuirks(0)
 r.generateSynthetic(R.SYNTH_NOISE_BALL, (1024, 1024, 1024), 2, 0x9E3779B9)
-r.setWindow(0, 4095); r.setAlpha(0.004)
+r.setWindow(0, 4095); r.setAlpha(float(sys.argv[3]) if len(sys.argv) > 3 else 0.004)
 if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
 r.setKernelVariant(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
