@@ -3,6 +3,10 @@
 #define VR_TSLAB_TU 99
 #include "../../volume-renderer_amd/csrc/vr_tslab.hip"
 namespace vr {
-template __global__ void raymarch_tslab_kernel<uint16_t, 0, 0, true, 0>(const FrameParams, const uint16_t *, const uint8_t *, const float4 *, float4 *, uint32_t *,
-                                                                         const uint32_t *, const int);
+#ifndef PROBE_NW
+#define PROBE_NW 8
+#define PROBE_LDSKB 80
+#endif
+template __global__ void raymarch_tslab_kernel<uint16_t, 0, 0, true, 0, PROBE_NW, PROBE_LDSKB>(const FrameParams, const uint16_t *, const uint8_t *, const float4 *, float4 *, uint32_t *,
+                                                                                               const uint32_t *, const int);
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Turn a tools/profile.sh summary into profiles/traffic.json (HBM bytes per launch of the
-dominant kernel) -- the `roofline.traffic` field bench.py prints for the same command.
+"""Turn the PMC passes of a tools/profile.sh / tools/extras_traffic.sh output directory into profiles/traffic.json
+(HBM bytes per launch of the kernel the bench line names) -- the `roofline.traffic` field bench.py prints for the
+same command.
 
 HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024:
   * FETCH_SIZE / WRITE_SIZE are reported in KiB and collected in SEPARATE --pmc passes;
@@ -10,27 +11,84 @@ HBM bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024:
     1,048,608.8 KiB (profiles/r01_v1_linear_summary.txt), while TCC_EA0_RDREQ x 128 B gives
     the full 2 GiB.  WRITE_SIZE needed no correction (gen_volume_kernel: 2,097,152 KiB for
     2 GiB written).
-usage: tools/pmc_traffic.py <summary.txt> <key>
+
+Which kernel: the measured work model launches several ray-march kernels in one run (the candidates it tries
+before it settles), so the counters are grouped by the FULL kernel name (every template argument), the family is
+the one the run's own JSON line names (`config.kernel`, read from the pass logs; or the third argument), the
+instance is the one with the most launches, and it must account for at least half of the run's ray-march launches
+-- otherwise no entry is written (round 3 quoted the last `raymarch_` line of the text summary: the relay kernel's
+six tuning launches instead of the settled fast kernel's 135).
+
+usage: tools/pmc_traffic.py <profile output dir> <key> [kernel family]
 """
+import csv
+import glob
 import json
+import os
 import re
 import sys
+from collections import defaultdict
 from pathlib import Path
 
-summary, key = sys.argv[1], sys.argv[2]
-vals = {}
-for line in Path(summary).read_text().splitlines():
-    if "raymarch_" not in line:
-        continue
-    m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
-    if m and int(m.group(2)) > 1:      # the timed launches, not the single instrumented one
-        vals[m.group(1)] = float(m.group(3))
-traffic = int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024)
-out = Path(__file__).resolve().parent.parent / "profiles" / "traffic.json"
-d = json.loads(out.read_text()) if out.exists() else {}
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from bench import kernel_source_hash   # the figure is only valid for the kernels it was measured on
+# bench.py's `config.kernel` -> the kernel's symbol
+ALIAS = {"raymarch_slab_tri_kernel": "raymarch_tslab_kernel"}
 
-d[key] = {"bytes": traffic, "kernel_source_hash": kernel_source_hash(), "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"]}
-out.write_text(json.dumps(d, indent=1) + "\n")
-print(key, traffic, vals)
+
+def kernel_from_logs(out):
+    for f in sorted(glob.glob(os.path.join(out, "*.log"))):
+        for line in Path(f).read_text(errors="replace").splitlines():
+            if line.startswith("{") and '"config"' in line:
+                try:
+                    return json.loads(line)["config"]["kernel"]
+                except (ValueError, KeyError):
+                    pass
+    return None
+
+
+def per_kernel(out, counter):
+    """{full kernel name: [values]} of one counter, from the pass that collected it"""
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(out, f"pmc_*{counter}*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter:
+                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    out, key = sys.argv[1], sys.argv[2]
+    family = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
+    if not family:
+        sys.exit(f"{key}: no kernel family given and no bench JSON line in {out}/*.log")
+    symbol = ALIAS.get(family, family)
+    vals, picked = {}, None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        acc = per_kernel(out, counter)
+        march = {k: v for k, v in acc.items() if "raymarch_" in k}
+        total = sum(len(v) for v in march.values())
+        mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
+        if not mine:
+            sys.exit(f"{key}: no launches of {symbol} in the {counter} pass ({sorted(march)})")
+        name = max(mine, key=lambda k: len(mine[k]))
+        if 2 * len(mine[name]) < total:
+            sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass -- not the settled kernel")
+        if picked is not None and name != picked:
+            sys.exit(f"{key}: the FETCH_SIZE and WRITE_SIZE passes settled on different instances:\n {picked}\n {name}")
+        picked = name
+        vals[counter] = (sum(mine[name]) / len(mine[name]), len(mine[name]), total)
+    traffic = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
+    root = Path(__file__).resolve().parent.parent
+    dst = root / "profiles" / "traffic.json"
+    d = json.loads(dst.read_text()) if dst.exists() else {}
+    sys.path.insert(0, str(root))
+    from bench import kernel_source_hash   # the figure is only valid for the kernels it was measured on
+
+    d[key] = {"bytes": traffic, "kernel": family, "instance": picked, "launches": vals["FETCH_SIZE"][1], "raymarch_launches_in_run": vals["FETCH_SIZE"][2],
+              "kernel_source_hash": kernel_source_hash(), "fetch_size_kib": round(vals["FETCH_SIZE"][0], 1), "write_size_kib": round(vals["WRITE_SIZE"][0], 1)}
+    dst.write_text(json.dumps(d, indent=1) + "\n")
+    print(key, family, traffic, {k: v[:2] for k, v in vals.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,7 @@ RendererCore::~RendererCore()
         if (d_fb_) (void)hipFree(d_fb_);
         if (d_tf_) (void)hipFree(d_tf_);
         if (d_tile_table_) (void)hipFree(d_tile_table_);
+        if (d_tile_table32_) (void)hipFree(d_tile_table32_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
@@ -618,7 +619,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    L.tri_slab = force_generic == 6 ? 1 : (force_generic == 7 ? 2 : 0);                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
+    L.tri_slab = force_generic == 6 ? 1 : (force_generic == 7 ? 2 : (force_generic == 8 ? 3 : (force_generic == 9 ? 4 : 0)));                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -927,6 +928,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
 {
     L.tile_table = nullptr;
     L.tile_table_blocks = 0;
+    L.tile_table32 = nullptr;
+    L.tile_table32_blocks = 0;
     if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
@@ -937,7 +940,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     const uint64_t shape_key = tileScheduleKey(P, rows, false);
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
-    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f)) {
+    const bool need32 = filter == 1 && res_bytes_ == 2 && tri_slab_candidate(P, L);   // 32x32-pixel tiles for the staged trilinear kernel's 16-wavefront workgroups
+    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table32_blocks_ == 0)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
         if (table.size() > tile_table_capacity_) {
@@ -949,11 +953,24 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
         check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
         check(hipMemcpy(d_tile_table_, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
         tile_table_blocks_ = table.size();
+        tile_table32_blocks_ = 0;
+        if (need32) {
+            std::vector<uint32_t> table32;
+            (void)buildTileSchedule(P, rows, table32, nullptr, 32u);
+            if (table32.size() > tile_table32_capacity_) {
+                if (d_tile_table32_) { check(hipFree(d_tile_table32_), "hipFree(tile table)"); d_tile_table32_ = nullptr; }
+                check(hipMalloc(reinterpret_cast<void **>(&d_tile_table32_), table32.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
+                tile_table32_capacity_ = table32.size();
+            }
+            check(hipMemcpy(d_tile_table32_, table32.data(), table32.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
+            tile_table32_blocks_ = table32.size();
+        }
         tile_table_key_ = shape_key;
         std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
+    if (need32 && tile_table32_blocks_ > 0) { L.tile_table32 = d_tile_table32_; L.tile_table32_blocks = (uint32_t)tile_table32_blocks_; }
     // Kernel choice per launch (all bit-identical; measured on cfg3 after the checked-head fix, tools/pose_sweep.py and
     // tools/shard_ms.py; `aligned` = central ray within ~23 degrees of a volume axis):
     //   * relay kernel (4 wavefronts per 8x8 tile) for launches far from filling the chip -- fewer than 256 active

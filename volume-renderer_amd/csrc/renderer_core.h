@@ -169,6 +169,8 @@ private:
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
+    uint32_t *d_tile_table32_ = nullptr;     // the same for 32x32-pixel tiles (vr_tslab.hip: 16-wavefront workgroups); built with the table above
+    size_t tile_table32_capacity_ = 0, tile_table32_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
     unsigned tile_active_ = 0;               // tiles with work in the cached schedule

@@ -100,12 +100,12 @@ uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
     return hsh;
 }
 
-unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples, unsigned tile_h)
 {
     unsigned active_tiles = 0;
     double longest = 0.0;
     const unsigned tiles_x = (unsigned)((P.img_w + (int)kFastTileW - 1) / (int)kFastTileW);
-    const unsigned tiles_y = (unsigned)((rows + (int)kFastTileH - 1) / (int)kFastTileH);
+    const unsigned tiles_y = (unsigned)((rows + (int)tile_h - 1) / (int)tile_h);
     // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
     // single tiles win -- balance across the XCDs matters more than sharing brick rows in one
     // L2 (0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4).
@@ -118,8 +118,8 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
     std::vector<double> tile_work((size_t)tiles_x * tiles_y, 0.0);
     for (unsigned ty = 0; ty < tiles_y; ty++) {
         // probe rows: top, middle, bottom of the tile (global rows of this shard)
-        const int ly0 = (int)(ty * kFastTileH);
-        const int pr[3] = {globalRow(P, ly0), globalRow(P, ly0 + (int)kFastTileH / 2), globalRow(P, ly0 + (int)kFastTileH - 1)};
+        const int ly0 = (int)(ty * tile_h);
+        const int pr[3] = {globalRow(P, ly0), globalRow(P, ly0 + (int)tile_h / 2), globalRow(P, ly0 + (int)tile_h - 1)};
         for (unsigned tx = 0; tx < tiles_x; tx++) {
             const double x0 = tx * (double)kFastTileW;
             double wmax = 0.0;

@@ -81,11 +81,13 @@ struct LaunchConfig {
     int sparse_shard;              // use the 4-wavefront relay kernel when the shape allows
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;
+    const uint32_t *tile_table32;  // device: the same for 32x32-pixel tiles (the staged trilinear kernel's 16-wavefront workgroups; nullptr = none)
+    uint32_t tile_table32_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip; host: aligned views, vr_set_kernel_variant 6 forces it); 2 = that kernel with staging switched off (variant 7)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip; host: aligned views, vr_set_kernel_variant 6 forces it); 2 = that kernel with staging switched off (variant 7); 3 = 32x16 tiles on a CU's whole LDS (variant 8); 4 = 32x32 tiles, 16 wavefronts, whole LDS (variant 9)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

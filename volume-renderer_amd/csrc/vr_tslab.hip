@@ -43,16 +43,15 @@
 
 namespace vr {
 
-constexpr int TS_NW = 8, TS_THREADS = 64 * TS_NW;         // one 32x16-pixel tile per workgroup
-// LDS per workgroup: two workgroups per CU (80 KiB each).  The ring has to hold three 144-slot layers of 160 B for the
-// 1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables take 20 KiB.  Three
-// workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose layers fit (512^3: 0.711 vs
-// 0.713 ms): the loop is bound by VALU issue, not by latency.
-#if defined(VR_EXPERIMENTS) && defined(VR_X_LDSKB)
-template <typename VoxelT> constexpr int ts_lds_bytes() { return VR_X_LDSKB * 1024 - 512; }
-#else
-template <typename VoxelT> constexpr int ts_lds_bytes() { return 80 * 1024 - 512; }
-#endif
+// Workgroup shapes (template parameters NW = wavefronts, LDSKB = KiB of LDS the workgroup declares):
+//   NW = 8,  LDSKB = 80:  one 32x16-pixel tile, two workgroups per CU.  The ring holds three 144-slot layers of 160 B for the
+//                         1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables take
+//                         20 KiB.  Three workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose
+//                         layers fit (512^3: 0.711 vs 0.713 ms): the loop is bound by VALU issue, not by latency.
+//   NW = 8,  LDSKB = 160: the same tile with the whole LDS of a CU (gfx950: 160 KiB per workgroup): ~330 slots of 160 B per
+//                         layer three deep -- what a 16-bit volume's OBLIQUE layers need (240-300 bricks as rectangles);
+//                         one workgroup = 8 wavefronts per CU.
+//   NW = 16, LDSKB = 160: a 32x32-pixel tile (1024 threads) on the whole LDS: 16 wavefronts per CU, larger footprints.
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
 #ifndef VR_X_FB_BATCH
 #define VR_X_FB_BATCH 4
@@ -60,22 +59,26 @@ constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of t
 constexpr int TS_FB_BATCH = VR_X_FB_BATCH;                            // samples whose taps a tile that is not staged requests together
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
-template <typename VoxelT, int MODE>
+template <typename VoxelT, int MODE, int NW, int LDSKB>
 struct TslabCfg {
+    static constexpr int THREADS = 64 * NW;                                       // 4 x NW/4 wavefronts of 8x8 pixels
+    static constexpr int TILE_H = 8 * (NW / 4);
+    static constexpr int WAVES_PER_SIMD = (LDSKB <= 80 ? 2 : 1) * NW / 4;
     static constexpr int SLOT = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // 80 B (u8) / 160 B (u16)
     static constexpr int CH = SLOT / 16;                                          // 16-byte chunks per slot
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
     static constexpr int MISC_BYTES = 512;
-    // one region carved per tile into [ring | plan | torus tables]: the tables' size follows the volume's dimensions
+    // one region carved per tile into [plan | torus tables | ring]: the tables' size follows the tile's own index ranges
     // (2 bytes per voxel index of the two minor axes, 4 per index of the major axis)
-    static constexpr int REGION = (ts_lds_bytes<VoxelT>() - LUT_BYTES - MISC_BYTES) / 16 * 16;
-    // 1-KiB DMA pieces per wavefront per layer: what three layers of the ring can hold (u16: 153 slots of 160 B, u8: 409 of 80 B)
-    static constexpr int MAX_PIECES = sizeof(VoxelT) == 1 ? 4 : 3;
-    static constexpr int LAYER_SLOTS_MAX = MAX_PIECES * TS_NW * 64 / CH;
+    static constexpr int REGION = (LDSKB * 1024 - 512 - LUT_BYTES - MISC_BYTES) / 16 * 16;
+    // 1-KiB DMA pieces per wavefront per layer: what three layers of the ring can hold (80 KiB: u16 153 slots of 160 B,
+    // u8 409 of 80 B)
+    static constexpr int MAX_PIECES = (NW == 8 && LDSKB == 80) ? (sizeof(VoxelT) == 1 ? 4 : 3) : ((REGION / 3 / SLOT) * CH + THREADS - 1) / THREADS;
+    static constexpr int LAYER_SLOTS_MAX = MAX_PIECES * NW * 64 / CH;
 };
 
-template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
-__global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const FrameParams P,
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB>
+__global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
                                                                        const VoxelT *__restrict__ vol,
                                                                        const uint8_t *__restrict__ src,
                                                                        const float4 *__restrict__ tf,
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
                                                                        const uint32_t *__restrict__ tile_table,
                                                                        const int no_stage)
 {
-    using C = TslabCfg<VoxelT, MODE>;
+    using C = TslabCfg<VoxelT, MODE, NW, LDSKB>;
+    constexpr int TS_NW = NW, TS_THREADS = C::THREADS;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
     __shared__ float corner[5][4];              // rows 0..3: G of the corner rays, row 4: E (voxel coordinates)
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
     const unsigned tx = t & 0xffffu, ty = t >> 16;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const int lx = (int)(tx * kFastTileW + (wave & 3u) * 8u + (lane & 7u));
-    const int ly = (int)(ty * kFastTileH + (wave >> 2) * 8u + (lane >> 3));
+    const int ly = (int)(ty * (unsigned)C::TILE_H + (wave >> 2) * 8u + (lane >> 3));
     int px = lx, py;
     if (P.stripe_count > 1) {
         const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
             else { lut[4 * e + 0] = q.x * a; lut[4 * e + 1] = q.y * a; lut[4 * e + 2] = q.z * a; }
             lut[4 * e + 3] = a;
         }
+        __syncthreads();                                                 // the checked head below classifies through the table
     }
 
     float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f;
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(TS_THREADS, 4) void raymarch_tslab_kernel(const Fra
 
     // ================================================================== the tile's load plan
     // corner rays in voxel coordinates: line E + t * G
-    const bool is_corner = (wave == 0 && lane == 0) || (wave == 3 && lane == 7) || (wave == 4 && lane == 56) || (wave == 7 && lane == 63);
+    const bool is_corner = (wave == 0 && lane == 0) || (wave == 3 && lane == 7) || (wave == NW - 4 && lane == 56) || (wave == NW - 1 && lane == 63);
     if (is_corner) {
-        const int cidx = (wave >= 4 ? 2 : 0) + ((wave & 3u) == 3u ? 1 : 0);
+        const int cidx = (wave >= NW - 4 ? 2 : 0) + ((wave & 3u) == 3u ? 1 : 0);
         float ex, ey, ez, gx, gy, gz;
         voxel_float(ray.ox, ray.oy, ray.oz, ex, ey, ez);
         voxel_float(ray.ox + ray.dx, ray.oy + ray.dy, ray.oz + ray.dz, gx, gy, gz);
@@ -776,7 +781,21 @@ template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
 {
-    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE>), dim3(L.tile_table_blocks), dim3(TS_THREADS), 0, st, P,
+    // L.tri_slab: 1 = 32x16 tiles, two workgroups per CU; 2 = the same with staging switched off; 3 = 32x16 tiles on the
+    // whole LDS of a CU; 4 = 32x32 tiles (16 wavefronts) on the whole LDS, from the 32-row tile table
+    if constexpr (sizeof(VoxelT) == 2) {                                 // (8-bit layers fit the 80-KiB ring at every pose measured)
+        if (L.tri_slab == 3) {
+            hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 8, 160>), dim3(L.tile_table_blocks), dim3(512), 0, st, P,
+                               (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table, 0);
+            return hipGetLastError();
+        }
+        if (L.tri_slab == 4 && L.tile_table32 != nullptr) {
+            hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 16, 160>), dim3(L.tile_table32_blocks), dim3(1024), 0, st, P,
+                               (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table32, 0);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 8, 80>), dim3(L.tile_table_blocks), dim3(512), 0, st, P,
                        (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table, L.tri_slab == 2 ? 1 : 0);
     return hipGetLastError();
 }
