@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment (needs a stats build of vr_tslab.hip: make TSLAB_TAG=_st TSLAB_DEFS="-DVR_EXPERIMENTS -DVR_X_STATS", then
 VR_CORE_LIB=.../libvr_core_st.so): per-tile load-plan statistics of the LDS-staged TRILINEAR kernel on the bench workload.
-  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale]"""
+  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale] [kernel variant: 6, 8, 9, 10]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -20,20 +20,22 @@ if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
 elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
     r.cameraOrient(0.0, *[float(v) for v in pose.split(",")])
-r.setKernelVariant(6)
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+TH = 32 if variant == 9 else 16              # rows per tile
+r.setKernelVariant(variant)
 r.render()
 print("kernel", r.last_kernel_name)
 _, spp = r.countSamples(per_pixel=True)
-st = spp[::16, ::32]
+st = spp[::TH, ::32]
 m = (st & 0x80000000) != 0
 v = st[m]
-staged, rz, slots, phases = v & 1, (v >> 4) & 15, (v >> 8) & 255, (v >> 16) & 4095
+staged, rz, half, slots, phases = v & 1, (v >> 4) & 7, (v >> 7) & 1, (v >> 8) & 255, (v >> 16) & 4095
 print("why not staged (1 corner rays disagree on / graze the major axis, 2 layer above the DMA piece limit, 3 ring not three layers deep, 4 layer beyond 64 KiB):", np.bincount((v >> 1) & 7)[:5])
-print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}); RZ histogram {np.bincount(rz)[:6]}; "
+print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}), of them in half layers {int((staged & half).sum())}; RZ histogram {np.bincount(rz)[:6]}; "
       f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
       f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
-clk, wall, iters, samp = spp[::16, 1::32][m].astype(np.float64), spp[::16, 2::32][m].astype(np.float64), spp[::16, 3::32][m].astype(np.float64), spp[::16, 4::32][m].astype(np.float64)
-setup = spp[::16, 5::32][m].astype(np.float64)
+clk, wall, iters, samp = spp[::TH, 1::32][m].astype(np.float64), spp[::TH, 2::32][m].astype(np.float64), spp[::TH, 3::32][m].astype(np.float64), spp[::TH, 4::32][m].astype(np.float64)
+setup = spp[::TH, 5::32][m].astype(np.float64)
 ok = wall > 0
 print(f"set-up before the march (ray, checked head, load plan, tables): mean {setup[ok].mean():.0f} ticks = {100 * setup[ok].sum() / (setup[ok].sum() + clk[ok].sum()):.1f} % of the tiles' time")
 for flag, name in ((1, "staged"), (0, "not staged")):

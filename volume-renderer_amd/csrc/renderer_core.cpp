@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -210,7 +211,9 @@ void RendererCore::freeVolume()
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
     vol12_failed_ = false;
     if (d_apron_) { (void)hipFree(d_apron_); d_apron_ = nullptr; apron_bytes_ = 0; }
+    for (void *&q : d_apron_perm_) if (q) { (void)hipFree(q); q = nullptr; }
     apron_failed_ = false;
+    apron_perm_failed_ = false;
 }
 
 void RendererCore::allocVolume(int nx, int ny, int nz, int bytes, int lay)
@@ -619,7 +622,8 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    L.tri_slab = force_generic == 6 ? 1 : (force_generic == 7 ? 2 : (force_generic == 8 ? 3 : (force_generic == 9 ? 4 : 0)));                 // kernel variant 6: TRILINEAR on the LDS-staged kernel wherever it is eligible (0: see refreshTileSchedule)
+    // kernel variants 6 .. 10: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
+    L.tri_slab = (force_generic >= 6 && force_generic <= 10) ? force_generic - 5 : 0;
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -676,6 +680,8 @@ float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
     refreshTileSchedule(P, L);
     refreshPacked12(P, L);
     refreshApron(P, L);
+    // (the half-layer shapes need the per-axis copies: without them -- allocation failed -- the round-3 choice)
+    if (L.tri_slab >= 3 && (L.apron_y == nullptr || L.apron_x == nullptr) && force_generic == 0) L.tri_slab = tri_path_candidate(P, L) ? 0 : 1;
     // the specialised kernels gather from the packed copy when their address tables fit (vr_kernels.hip: dispatch_fast3)
     last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
     tuneChoose(P, L);
@@ -714,14 +720,17 @@ void RendererCore::tuneRecord(uint64_t key, int cand, float ms)
     TuneEntry &e = it->second;
     e.best_ms[cand] = e.tries[cand] == 0 ? ms : std::min(e.best_ms[cand], ms);
     e.tries[cand]++;
-    constexpr int kTries = 2;
     bool all = true;
-    for (int c = 0; c < e.ncand; c++) all = all && e.tries[c] >= kTries;
+    for (int c = 0; c < e.ncand; c++) all = all && e.tries[c] >= kTuneTries;
     if (all) {
-        int best = 0;
-        for (int c = 1; c < e.ncand; c++)
-            if (e.best_ms[c] < e.best_ms[best] * 0.99f) best = c;        // ties go to the heuristic's choice
+        // the heuristic's choice wins ties: a rival has to be 2 % faster, more than two event timings of one kernel differ by
+        int heur = 0;
+        for (int c = 0; c < e.ncand; c++) if (e.cand[c] == e.heur) heur = c;
+        int best = heur;
+        for (int c = 0; c < e.ncand; c++)
+            if (c != heur && e.best_ms[c] < e.best_ms[best] * (best == heur ? 0.98f : 1.0f)) best = c;
         e.settled = best;
+        e.frames_settled = 0;
     }
 }
 
@@ -744,19 +753,28 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
 {
     tune_measure_ = false;
     tuneCollect();
+    const int prior = (L.sparse_shard ? 1 : 0) | (L.pipelined ? 2 : 0) | (L.short_batches ? 4 : 0) | (L.tri_slab << 3);
+    last_choice_ = prior;
     if (!autotune || force_generic != 0 || !L.tile_table) return;
     // candidates, the heuristic's choice (what buildFrame / refreshTileSchedule left in L) first
-    const int prior = (L.sparse_shard ? 1 : 0) | (L.pipelined ? 2 : 0) | (L.short_batches ? 4 : 0) | (L.tri_slab ? 8 : 0);
-    int cand[4], n = 0;
-    auto add = [&](int c) { for (int k = 0; k < n; k++) if (cand[k] == c) return; if (n < 4) cand[n++] = c; };
+    int cand[kTuneCand], n = 0;
+    auto add = [&](int c) { for (int k = 0; k < n; k++) if (cand[k] == c) return; if (n < kTuneCand) cand[n++] = c; };
     if (fast_path_eligible(P, L)) {
         const bool relay_ok = !L.big_offsets && !(P.skip_empty != 0 && L.skip_grid != nullptr);
         add(prior & (relay_ok ? 7 : 6));
         add(P.alpha_scale >= 0.5f ? 4 : 2);                              // fast kernel: four-sample batches / pipelined loop
         add(0);                                                          // fast kernel, plain loop
         if (relay_ok) add(1);
-    } else if (L.filter == 1 && L.apron != nullptr && tri_slab_candidate(P, L) && tri_path_candidate(P, L)) {
-        add(prior & 8); add(8); add(0);                                  // LDS-staged / batched trilinear kernel
+    } else if (L.filter == 1 && L.apron != nullptr && tri_slab_candidate(P, L)) {
+        // TRILINEAR: the LDS-staged kernel in its shapes, the batched kernel where it can run
+        add(prior & ~7);
+        add(1 << 3);
+        if (tri_path_candidate(P, L)) add(0);
+        if (L.apron_y != nullptr && L.apron_x != nullptr) {
+            add(3 << 3);
+            if (L.tile_table32 != nullptr) add(4 << 3);
+            add(5 << 3);
+        }
     }
     if (n < 2) return;
     uint64_t key = tileScheduleKey(P, launch_local_rows(P), false);
@@ -770,18 +788,54 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         mix((uint64_t)(r1 * 8.0) << 8 | (uint64_t)(r2 * 8.0));
     }
     mix((uint64_t)(std::log2((double)std::max(tile_active_, 1u)) * 3.0));
-    uint32_t abits; std::memcpy(&abits, &P.alpha_scale, 4);
-    mix(abits); mix((uint64_t)(uint32_t)P.min_val << 32 | (uint32_t)P.max_val);
+    // opacity and window enter in coarse buckets (how early rays end, how wide the classification table is): a slider dragged
+    // through hundreds of values stays in one or two entries instead of opening a new one -- and a new exploration -- per frame
+    const double a = (double)P.alpha_scale;
+    mix((uint64_t)(a >= 0.5 ? 1000 : (a > 0.0 ? (int)std::floor(std::log2(a) * 0.5) + 500 : 0)));
+    mix((uint64_t)std::floor(std::log2((double)std::max(P.max_val - P.min_val, 1))) << 8 | (uint64_t)(L.use_lut != 0) << 1 | (uint64_t)(L.lut_noclamp != 0));
     mix((uint64_t)P.nx << 40 | (uint64_t)P.ny << 20 | (uint64_t)P.nz);
     mix((uint64_t)L.filter | (uint64_t)L.mip << 1 | (uint64_t)(P.tf_len > 1) << 2 | (uint64_t)(P.skip_empty != 0) << 3 | (uint64_t)L.layout << 4 |
         (uint64_t)L.bytes_per_voxel << 5 | (uint64_t)(L.packed12 != nullptr) << 8 | (uint64_t)(L.apron != nullptr) << 9 | (uint64_t)P.fb_format << 10 |
-        (uint64_t)P.view_top << 11 | (uint64_t)P.view_bottom << 12 | (uint64_t)prior << 16);
-    if (tune_.size() > 512) tune_.clear();
-    TuneEntry &e = tune_[key];
-    if (e.ncand == 0) { e.ncand = n; for (int k = 0; k < n; k++) e.cand[k] = cand[k]; }
+        (uint64_t)P.view_top << 11 | (uint64_t)P.view_bottom << 12 | (uint64_t)(L.apron_y != nullptr) << 13 | (uint64_t)prior << 16);
+    tune_clock_++;
+    tune_same_key_run_ = key == tune_last_key_ ? tune_same_key_run_ + 1 : 0;
+    tune_last_key_ = key;
+    auto it = tune_.find(key);
+    if (it == tune_.end()) {
+        // a configuration that is only passing through (an orbiting camera crossing a pose bucket, a slider crossing an opacity
+        // bucket) gets the heuristic's choice; exploring starts when the same key has come three times in a row
+        if (tune_same_key_run_ < 2) return;
+        if (tune_.size() >= (size_t)kTuneEntries) {                      // evict the least recently used eighth
+            std::vector<std::pair<uint64_t, uint64_t>> age;
+            age.reserve(tune_.size());
+            for (auto &kv : tune_) age.emplace_back(kv.second.last_use, kv.first);
+            std::nth_element(age.begin(), age.begin() + kTuneEntries / 8, age.end());
+            for (int k = 0; k < kTuneEntries / 8; k++) tune_.erase(age[(size_t)k].second);
+        }
+        it = tune_.emplace(key, TuneEntry{}).first;
+        TuneEntry &e = it->second;
+        e.ncand = n;
+        for (int k = 0; k < n; k++) e.cand[k] = cand[k];
+        e.heur = cand[0];
+        // shuffled measuring order (Fisher-Yates on a counter-seeded LCG)
+        uint64_t r = key ^ (tune_clock_ * 0x9E3779B97F4A7C15ull);
+        for (int k = n - 1; k > 0; k--) {
+            r = r * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(e.cand[k], e.cand[(int)((r >> 33) % (uint64_t)(k + 1))]);
+        }
+    }
+    TuneEntry &e = it->second;
+    e.last_use = tune_clock_;
     int use;
     if (e.settled >= 0) {
         use = e.settled;
+        // one re-measurement at sustained clocks: whatever settled during the clock ramp is checked again, once
+        if (!e.revalidated && ++e.frames_settled >= kTuneRevalidateFrames) {
+            e.revalidated = true;
+            for (int c = 0; c < e.ncand; c++) { e.tries[c] = 0; e.best_ms[c] = 0.0f; }
+            e.settled = -1;
+            e.next = 0;
+        }
     } else if (tune_count_ >= kTuneSlots) {                              // every event pair is in flight: best so far
         use = 0;
         for (int c = 1; c < e.ncand; c++)
@@ -792,7 +846,8 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         tune_measure_ = true; tune_key_ = key; tune_cand_ = use;
     }
     const int c = e.cand[use];
-    L.sparse_shard = (c & 1) ? 1 : 0; L.pipelined = (c & 2) ? 1 : 0; L.short_batches = (c & 4) ? 1 : 0; L.tri_slab = (c & 8) ? 1 : 0;
+    L.sparse_shard = (c & 1) ? 1 : 0; L.pipelined = (c & 2) ? 1 : 0; L.short_batches = (c & 4) ? 1 : 0; L.tri_slab = (c >> 3) & 15;
+    last_choice_ = c;
 }
 
 // 12-bit packed copy (vr_set_pack12, default on): when every voxel of a bricked u16 volume is
@@ -834,6 +889,7 @@ void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
 void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
 {
     L.apron = nullptr;
+    L.apron_y = L.apron_x = nullptr;
     L.apron_bytes = 0;
     last_apron_bytes_ = 0;
     if (!tri_apron || apron_failed_ || vol_layout_ != 1 || !(tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
@@ -849,7 +905,7 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
         hipError_t e = hipMemsetAsync(static_cast<char *>(d_apron_) + bytes, 0, 16, stream());
         if (e == hipSuccess)
             e = launch_relayout_apron(d_vol_, d_apron_, res_bytes_, (uint32_t)res_dims_[0], (uint32_t)res_dims_[1], (uint32_t)res_dims_[2],
-                                      vol_layout_, (uint32_t)bricksX(res_dims_[0]), (uint32_t)bricksY(res_dims_[1]), stream());
+                                      vol_layout_, (uint32_t)bricksX(res_dims_[0]), (uint32_t)bricksY(res_dims_[1]), 0, stream());
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         if (e != hipSuccess) { (void)hipFree(d_apron_); d_apron_ = nullptr; }
         check(e, "relayout_apron_kernel");
@@ -858,6 +914,34 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     L.apron = d_apron_;
     L.apron_bytes = (uint64_t)apron_bytes_;
     last_apron_bytes_ = apron_bytes_;
+    // Half layers of the staged kernel (vr_tslab.hip, 16-bit volumes): two more copies with the bricks' planes along y / x
+    // slowest, so that half a brick along any major axis is 80 contiguous bytes.  Built the first time a view is oblique
+    // to the volume axes (or kernel variants 8 .. 10 ask for them); +2 x 1.25 volumes of HBM.
+    const bool oblique = viewAxisAlignment(P) < 0.92;
+    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 10) || (force_generic == 0 && oblique));
+    if (want_perm && !apron_perm_failed_) {
+        for (int o = 0; o < 2 && !apron_perm_failed_; o++) {
+            if (d_apron_perm_[o]) continue;
+            if (hipMalloc(&d_apron_perm_[o], bytes + 16) != hipSuccess) {
+                (void)hipGetLastError();
+                d_apron_perm_[o] = nullptr;
+                apron_perm_failed_ = true;
+                break;
+            }
+            hipError_t e = hipMemsetAsync(static_cast<char *>(d_apron_perm_[o]) + bytes, 0, 16, stream());
+            if (e == hipSuccess)
+                e = launch_relayout_apron(d_vol_, d_apron_perm_[o], res_bytes_, (uint32_t)res_dims_[0], (uint32_t)res_dims_[1], (uint32_t)res_dims_[2],
+                                          vol_layout_, (uint32_t)bricksX(res_dims_[0]), (uint32_t)bricksY(res_dims_[1]), o + 1, stream());
+            if (e == hipSuccess) e = hipStreamSynchronize(stream());
+            if (e != hipSuccess) { (void)hipFree(d_apron_perm_[o]); d_apron_perm_[o] = nullptr; }
+            check(e, "relayout_apron_kernel");
+        }
+    }
+    if (d_apron_perm_[0] && d_apron_perm_[1]) {
+        L.apron_y = d_apron_perm_[0];
+        L.apron_x = d_apron_perm_[1];
+        last_apron_bytes_ += 2 * apron_bytes_;
+    }
 }
 
 // Exact empty-space skipping (vr_set_skip_empty): the fast kernel may skip a batch of
@@ -944,26 +1028,23 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table32_blocks_ == 0)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
-        if (table.size() > tile_table_capacity_) {
-            if (d_tile_table_) { check(hipFree(d_tile_table_), "hipFree(tile table)"); d_tile_table_ = nullptr; }
-            check(hipMalloc(reinterpret_cast<void **>(&d_tile_table_), table.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
-            tile_table_capacity_ = table.size();
-        }
-        // synchronous copy: `table` is a pageable temporary
+        // synchronous copies: the tables are pageable temporaries
         check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
-        check(hipMemcpy(d_tile_table_, table.data(), table.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
-        tile_table_blocks_ = table.size();
+        auto upload = [&](uint32_t *&d, size_t &capacity, size_t &blocks, const std::vector<uint32_t> &t) {
+            if (t.size() > capacity) {
+                if (d) { check(hipFree(d), "hipFree(tile table)"); d = nullptr; }
+                check(hipMalloc(reinterpret_cast<void **>(&d), t.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
+                capacity = t.size();
+            }
+            if (!t.empty()) check(hipMemcpy(d, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
+            blocks = t.size();
+        };
+        upload(d_tile_table_, tile_table_capacity_, tile_table_blocks_, table);
         tile_table32_blocks_ = 0;
         if (need32) {
-            std::vector<uint32_t> table32;
-            (void)buildTileSchedule(P, rows, table32, nullptr, 32u);
-            if (table32.size() > tile_table32_capacity_) {
-                if (d_tile_table32_) { check(hipFree(d_tile_table32_), "hipFree(tile table)"); d_tile_table32_ = nullptr; }
-                check(hipMalloc(reinterpret_cast<void **>(&d_tile_table32_), table32.size() * sizeof(uint32_t)), "hipMalloc(tile table)");
-                tile_table32_capacity_ = table32.size();
-            }
-            check(hipMemcpy(d_tile_table32_, table32.data(), table32.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(tile table)");
-            tile_table32_blocks_ = table32.size();
+            std::vector<uint32_t> t32;
+            (void)buildTileSchedule(P, rows, t32, nullptr, 32u);
+            upload(d_tile_table32_, tile_table32_capacity_, tile_table32_blocks_, t32);
         }
         tile_table_key_ = shape_key;
         std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
@@ -980,12 +1061,21 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     //     early (alpha >= 0.5: the speculative batch is wasted, 0.198 vs 0.189 ms): equal at the default pose
     //     (0.454 ms), 3-14 % faster over oblique poses, 12 % at an N = 4 shard (0.163 vs 0.185 ms).
     const bool aligned = viewAxisAlignment(P) >= 0.92;
-    // TRILINEAR: the LDS-staged kernel (vr_tslab.hip) when the view is aligned with a volume axis -- its tiles' brick
-    // layers then fit the ring three deep (cfg3 default pose: every tile staged, 1.36 vs 1.93 ms); an oblique view's
-    // layers are ~1.5x as large, most tiles would march on global taps (4.1 vs 3.2 ms), so it keeps the batched kernel.
-    // Volumes the batched kernel cannot take (beyond 32-bit offsets, or with a transfer function) always go staged.
-    // 8-bit volumes: a slot is 80 B, nearly every oblique tile fits as well (orbit poses 1.2-1.6 ms against 2.1 batched).
-    if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L) && (aligned || L.bytes_per_voxel == 1 || !tri_path_candidate(P, L))) L.tri_slab = 1;
+    // TRILINEAR, first guess (the work model then measures): the LDS-staged kernel (vr_tslab.hip) -- whole brick layers, two
+    // workgroups per CU -- when the view is aligned with a volume axis (cfg3 default pose: every tile staged, 1.25 vs 1.93 ms on
+    // the batched kernel) and for 8-bit volumes at every pose (80-byte slots: orbit poses 1.1-1.4 ms against 2.1).  A 16-bit
+    // volume's oblique layers do not fit three deep (240-400 bricks of 160 B): those views take the per-axis copies and half
+    // layers (round 4: orbit poses 1.43-1.62 ms against 2.9-3.4 whole-layer / 2.6-3.0 batched), on a CU's whole LDS when the
+    // view runs near a body diagonal of the volume (2.47 ms against 2.9).
+    if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L)) {
+        if (aligned || L.bytes_per_voxel == 1) {
+            L.tri_slab = 1;
+        } else {
+            double r1, r2;
+            viewAxisRatios(P, r1, r2);
+            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 5 : 3;
+        }
+    }
     // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is
     // a single under-filled round of long serial rays -- few active tiles, scaled by how long the rays are (1045 samples
     // on the configuration the 256 / 1024 were measured on; a 256^3 volume's 262-sample rays want 4x fewer tiles)

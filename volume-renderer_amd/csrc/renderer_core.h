@@ -98,6 +98,7 @@ public:
     double measureStreamRead(int reps);
     void assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream);
     const char *lastKernelName() const { return last_kernel_; }
+    int lastLaunchChoice() const { return last_choice_; }     // 1 relay, 2 pipelined loop, 4 short batches, tri_slab << 3
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     size_t lastApronBytes() const { return last_apron_bytes_; }
     bool hasDevice() const { return device_ >= 0; }
@@ -162,6 +163,8 @@ private:
     size_t last_packed12_bytes_ = 0;         // packed copy used by the last launch (0 = none)
     void refreshPacked12(const FrameParams &P, LaunchConfig &L);
     void *d_apron_ = nullptr;                // TRILINEAR's apron copy of the volume (vr_frame.h: apron_voxels)
+    void *d_apron_perm_[2] = {nullptr, nullptr};   // the same with the bricks' planes along y / x slowest (half layers of the staged kernel; 16-bit volumes, oblique views)
+    bool apron_perm_failed_ = false;
     size_t apron_bytes_ = 0, last_apron_bytes_ = 0;
     bool apron_failed_ = false;
     void refreshApron(const FrameParams &P, LaunchConfig &L);
@@ -169,7 +172,7 @@ private:
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
-    uint32_t *d_tile_table32_ = nullptr;     // the same for 32x32-pixel tiles (vr_tslab.hip: 16-wavefront workgroups); built with the table above
+    uint32_t *d_tile_table32_ = nullptr;     // the same for 32x32-pixel tiles (vr_tslab.hip: 16-wavefront workgroups; 16-bit volumes); built with the table above
     size_t tile_table32_capacity_ = 0, tile_table32_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
@@ -180,10 +183,19 @@ private:
     // ---- measured work model (kernel variant 0): every candidate kernel of a configuration renders the same bits, so
     // the first frames of a configuration double as measurements -- each candidate is timed a few times (HIP events on
     // the launch stream, polled without blocking), the fastest is kept until the configuration changes.
-    // A candidate = bit set: 1 relay kernel, 2 pipelined batch loop, 4 four-sample batches, 8 LDS-staged trilinear kernel.
+    // A candidate = bit set: 1 relay kernel, 2 pipelined batch loop, 4 four-sample batches; bits 3 .. 6: LaunchConfig::tri_slab
+    // (0 = batched trilinear kernel, 1 / 3 / 4 / 5 = the LDS-staged kernel in one of its shapes).
+    // An entry settles on the fastest candidate after kTuneTries measurements of each (in an order shuffled per entry, so no
+    // candidate is always the one measured on cold clocks), is measured ONCE more kTuneRevalidateFrames frames later (the first
+    // ~25 frames after idle run ~15 % slow while the clocks ramp) and is evicted least-recently-used first.
+    static constexpr int kTuneCand = 6, kTuneTries = 2, kTuneRevalidateFrames = 96, kTuneEntries = 512;
     struct TuneEntry {
-        int ncand = 0, cand[4] = {0, 0, 0, 0}, tries[4] = {0, 0, 0, 0}, settled = -1, next = 0;
-        float best_ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int ncand = 0, cand[kTuneCand] = {}, tries[kTuneCand] = {}, settled = -1, next = 0;
+        int heur = 0;                        // the heuristic's choice (a candidate value): it wins ties
+        float best_ms[kTuneCand] = {};
+        int frames_settled = 0;              // launches since it settled
+        bool revalidated = false;
+        uint64_t last_use = 0;               // launch counter at its last use (eviction order)
     };
     std::map<uint64_t, TuneEntry> tune_;
     static constexpr int kTuneSlots = 12;    // asynchronous measurements that may be in flight (a burst of renderAsync calls)
@@ -193,6 +205,9 @@ private:
     bool tune_measure_ = false;              // the launch being prepared is a measurement of candidate tune_cand_ of entry tune_key_
     uint64_t tune_key_ = 0;
     int tune_cand_ = -1;
+    uint64_t tune_clock_ = 0, tune_last_key_ = 0;   // launches seen; the previous launch's key and for how many launches in a row
+    int tune_same_key_run_ = 0;
+    int last_choice_ = 0;                    // candidate bits of the last launch (vr_get_launch_choice)
     void tuneChoose(const FrameParams &P, LaunchConfig &L);
     void tuneRecord(uint64_t key, int cand, float ms);
     void tuneCollect();

@@ -330,7 +330,7 @@ int vr_set_autotune(vr_handle h, int enable)
 int vr_set_kernel_variant(vr_handle h, int variant)
 {
     return guarded(h, [&](vr::RendererCore &c) {
-        if (variant < 0 || variant > 9 || variant == 4) throw std::invalid_argument("unknown kernel variant");   // 4: retired in round 3
+        if (variant < 0 || variant > 10 || variant == 4) throw std::invalid_argument("unknown kernel variant");   // 4: retired in round 3
         c.force_generic = variant;
     });
 }
@@ -526,6 +526,7 @@ unsigned int vr_checksum(const unsigned char *data, unsigned int bytes)
 
 void vr_free(void *p) { std::free(p); }
 
+int vr_get_launch_choice(vr_handle h) { return h ? h->core.lastLaunchChoice() : 0; }
 const char *vr_last_kernel_name(vr_handle h) { return h ? h->core.lastKernelName() : ""; }
 
 }  // extern "C"

@@ -53,9 +53,11 @@ hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pix
 // one empty launch per translation unit: loads every code object of the library (vr_load_shader)
 hipError_t launch_warm_modules(hipStream_t st);
 
-// TRILINEAR's apron copy: 5x4x4-stored 4x4x4 bricks (vr_device.h); `out` holds apron_voxels(nx, ny, nz) voxels
+// TRILINEAR's apron copy: 5x4x4-stored 4x4x4 bricks (vr_device.h); `out` holds apron_voxels(nx, ny, nz) voxels.
+// order 0: x fastest (5 wide: the apron), y, z slowest; 1: x (apron), z, y slowest; 2: y (apron), z, x slowest -- the
+// bricks themselves stay in x-y-z order (vr_tslab.hip: half a brick along the slowest axis is contiguous)
 hipError_t launch_relayout_apron(const void *vol, void *out, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
-                                 uint32_t bnx, uint32_t bny, hipStream_t st);
+                                 uint32_t bnx, uint32_t bny, int order, hipStream_t st);
 
 // multi-GPU assembly on the root device (vr_group.cpp): gathered = n rank-major compact shards of local_rows x W
 // pixels with `channels` floats each (2 = (grey, alpha), 4 = RGBA); stripe_rows = 0: contiguous row blocks,

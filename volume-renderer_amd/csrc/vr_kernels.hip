@@ -1902,12 +1902,13 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
 // the resident volume (linear or cube-bricked) -> TRILINEAR's apron copy (vr_device.h: build_axis_tables_apron)
 template <typename VoxelT>
 __global__ __launch_bounds__(256) void relayout_apron_kernel(const VoxelT *__restrict__ vol, VoxelT *__restrict__ out, uint32_t nx, uint32_t ny,
-                                                             uint32_t nz, int layout, uint32_t bnx, uint32_t bny, uint64_t total)
+                                                             uint32_t nz, int layout, uint32_t bnx, uint32_t bny, int order, uint64_t total)
 {
     const uint32_t abx = (nx + 3u) >> 2, aby = (ny + 3u) >> 2;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t brick = s / APRON_BRICK_VOXELS;
-        const uint32_t r = (uint32_t)(s % APRON_BRICK_VOXELS), xl = r % 5u, yl = (r / 5u) & 3u, zl = r / 20u;
+        const uint32_t r = (uint32_t)(s % APRON_BRICK_VOXELS), pl = r % 5u, ql = (r / 5u) & 3u, ml = r / 20u;   // fastest (apron), middle, slowest
+        const uint32_t xl = order == 2 ? ml : pl, yl = order == 0 ? ql : (order == 1 ? ml : pl), zl = order == 0 ? ml : ql;
         const uint32_t bx = (uint32_t)(brick % abx), by = (uint32_t)((brick / abx) % aby), bz = (uint32_t)(brick / ((uint64_t)abx * aby));
         const uint32_t i = min(4u * bx + xl, nx - 1u), j = min(4u * by + yl, ny - 1u), k = min(4u * bz + zl, nz - 1u);   // edge voxels repeat
         out[s] = vol[storage_index(layout, i, j, k, nx, ny, bnx, bny)];
@@ -1915,14 +1916,14 @@ __global__ __launch_bounds__(256) void relayout_apron_kernel(const VoxelT *__res
 }
 
 hipError_t launch_relayout_apron(const void *vol, void *out, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
-                                 uint32_t bnx, uint32_t bny, hipStream_t st)
+                                 uint32_t bnx, uint32_t bny, int order, hipStream_t st)
 {
     const uint64_t total = apron_voxels((int)nx, (int)ny, (int)nz);
     const unsigned blocks = (unsigned)std::min<uint64_t>((total + 255) / 256, 256u * 64u);
     if (bytes_per_voxel == 1)
-        hipLaunchKernelGGL(relayout_apron_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t *)vol, (uint8_t *)out, nx, ny, nz, layout, bnx, bny, total);
+        hipLaunchKernelGGL(relayout_apron_kernel<uint8_t>, dim3(blocks), dim3(256), 0, st, (const uint8_t *)vol, (uint8_t *)out, nx, ny, nz, layout, bnx, bny, order, total);
     else
-        hipLaunchKernelGGL(relayout_apron_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)vol, (uint16_t *)out, nx, ny, nz, layout, bnx, bny, total);
+        hipLaunchKernelGGL(relayout_apron_kernel<uint16_t>, dim3(blocks), dim3(256), 0, st, (const uint16_t *)vol, (uint16_t *)out, nx, ny, nz, layout, bnx, bny, order, total);
     return hipGetLastError();
 }
 

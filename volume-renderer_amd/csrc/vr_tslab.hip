@@ -32,6 +32,16 @@
 //     iterated positions (k * 2^-23 * N voxels) for the difference between the lines and the marched positions;
 //   * no clamps in the prefix: u = max(f - 0.5, 0) makes the low edge exact (cell 0 with weight 0 == the shader's two
 //     clamped taps of voxel 0), the high edge is the apron column (x) or a duplicated last table entry (y, z).
+//   * round 4, 16-bit volumes (PERM instances): HALF LAYERS.  An oblique tile's layers are 240-400 bricks as rectangles
+//     (tools/model/tslab_footprint2.py); three of them at 160 B a slot do not fit 80 KiB, and the whole LDS of a CU for
+//     one 8-wavefront workgroup costs 1.5x in issue rate (1.25 -> 1.86 ms at the default pose).  So a tile whose whole
+//     layers do not fit marches in layers TWO voxels thick: a slot is half a brick (80 B), the ring holds three
+//     300-slot half layers in 80 KiB, twice the phases.  Half a brick must be contiguous for the DMA, i.e. the brick's
+//     planes along the MAJOR axis must be its slowest dimension: one apron copy per major axis (order 0: x fastest with
+//     the apron, y, z slowest = the copy above; order 1: x, z, y slowest; order 2: y fastest with the apron, z, x
+//     slowest), built on first use.  The pair of taps one LDS address yields then lies along the tile's first minor axis
+//     (x, or y when the rays advance along x); the lerp order stays x, y, z.  The thickness is chosen per tile: whole
+//     layers where they fit (fewer barriers), half layers otherwise.
 // A tile whose corner rays disagree on the major axis or its sign, or whose layers do not fit the ring three deep,
 // marches its prefix on global taps (same arithmetic, slower); head and tail always do.
 // Correctness does not depend on the rectangles being tight, only on their being supersets; the parity tests compare
@@ -47,11 +57,15 @@ namespace vr {
 //   NW = 8,  LDSKB = 80:  one 32x16-pixel tile, two workgroups per CU.  The ring holds three 144-slot layers of 160 B for the
 //                         1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables take
 //                         20 KiB.  Three workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose
-//                         layers fit (512^3: 0.711 vs 0.713 ms): the loop is bound by VALU issue, not by latency.
-//   NW = 8,  LDSKB = 160: the same tile with the whole LDS of a CU (gfx950: 160 KiB per workgroup): ~330 slots of 160 B per
-//                         layer three deep -- what a 16-bit volume's OBLIQUE layers need (240-300 bricks as rectangles);
-//                         one workgroup = 8 wavefronts per CU.
-//   NW = 16, LDSKB = 160: a 32x32-pixel tile (1024 threads) on the whole LDS: 16 wavefronts per CU, larger footprints.
+//                         layers fit (512^3: 0.711 vs 0.713 ms): the loop is bound by VALU issue, not by latency -- but ONE
+//                         workgroup per CU (8 wavefronts) is 1.5x slower (1.25 -> 1.86 ms): two wavefronts per SIMD do not
+//                         cover each other's LDS latencies.
+//   NW = 16, LDSKB = 160: a 32x32-pixel tile (1024 threads) on a CU's whole LDS (gfx950: 160 KiB per workgroup): 16 wavefronts
+//                         per CU, 660 half-brick slots per layer three deep; footprints are larger and a frame is three rounds
+//                         of long tiles (+ 10 % at the default pose), but the few poses whose 32x16 tiles do not fit 80 KiB
+//                         even in half layers do fit here.
+//   NW = 8,  LDSKB = 160: the 32x16 tile with the whole LDS: everything fits, at 8 wavefronts per CU (views along a body
+//                         diagonal of the volume: 2.47 ms against 2.7-2.9 for the other two).
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
 #ifndef VR_X_FB_BATCH
 #define VR_X_FB_BATCH 4
@@ -59,35 +73,45 @@ constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of t
 constexpr int TS_FB_BATCH = VR_X_FB_BATCH;                            // samples whose taps a tile that is not staged requests together
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
-template <typename VoxelT, int MODE, int NW, int LDSKB>
+template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM>
 struct TslabCfg {
     static constexpr int THREADS = 64 * NW;                                       // 4 x NW/4 wavefronts of 8x8 pixels
     static constexpr int TILE_H = 8 * (NW / 4);
     static constexpr int WAVES_PER_SIMD = (LDSKB <= 80 ? 2 : 1) * NW / 4;
-    static constexpr int SLOT = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // 80 B (u8) / 160 B (u16)
-    static constexpr int CH = SLOT / 16;                                          // 16-byte chunks per slot
+    static constexpr int BRICK_BYTES = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // a brick of the apron copies: 80 B (u8) / 160 B (u16)
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
     static constexpr int MISC_BYTES = 512;
     // one region carved per tile into [plan | torus tables | ring]: the tables' size follows the tile's own index ranges
     // (2 bytes per voxel index of the two minor axes, 4 per index of the major axis)
     static constexpr int REGION = (LDSKB * 1024 - 512 - LUT_BYTES - MISC_BYTES) / 16 * 16;
     // 1-KiB DMA pieces per wavefront per layer: what three layers of the ring can hold (80 KiB: u16 153 slots of 160 B,
-    // u8 409 of 80 B)
-    static constexpr int MAX_PIECES = (NW == 8 && LDSKB == 80) ? (sizeof(VoxelT) == 1 ? 4 : 3) : ((REGION / 3 / SLOT) * CH + THREADS - 1) / THREADS;
-    static constexpr int LAYER_SLOTS_MAX = MAX_PIECES * NW * 64 / CH;
+    // u8 409 of 80 B); a third of the region in 16-byte chunks whatever the slot size
+    static constexpr int MAX_PIECES = (NW == 8 && LDSKB == 80 && !PERM) ? (sizeof(VoxelT) == 1 ? 4 : 3) : (REGION / 3 / 16 + THREADS - 1) / THREADS;
+    // half layers (two voxels thick, half-brick slots): per-major-axis copies, and a half brick must be whole 16-byte chunks
+    static constexpr bool HALF_OK = PERM && (BRICK_BYTES / 2) % 16 == 0;
 };
 
-template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB>
-__global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
+#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)   // per-tile statistics build (tools/tslab_stats.py)
+#define VR_TSLAB_STAT(...) __VA_ARGS__
+#else
+#define VR_TSLAB_STAT(...)
+#endif
+
+// PERM: per-major-axis apron copies (src = order 0, src_y = order 1, src_x = order 2), the tap pair along the first minor axis,
+// layer thickness 4 or 2 per tile; otherwise the order-0 copy for every tile, pairs along x, whole layers
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB, bool PERM>
+__global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
                                                                        const VoxelT *__restrict__ vol,
                                                                        const uint8_t *__restrict__ src,
+                                                                       const uint8_t *__restrict__ src_y,
+                                                                       const uint8_t *__restrict__ src_x,
                                                                        const float4 *__restrict__ tf,
                                                                        float4 *__restrict__ fb,
                                                                        uint32_t *__restrict__ spp,
                                                                        const uint32_t *__restrict__ tile_table,
                                                                        const int no_stage)
 {
-    using C = TslabCfg<VoxelT, MODE, NW, LDSKB>;
+    using C = TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>;
     constexpr int TS_NW = NW, TS_THREADS = C::THREADS;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
@@ -98,9 +122,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
 
     const uint32_t t = tile_table[blockIdx.x];
     if (t == 0xffffffffu) return;                                       // padding block
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-    const uint64_t st_entry = clock64();
-#endif
+    VR_TSLAB_STAT(const uint64_t st_entry = clock64();)
     const unsigned tx = t & 0xffffu, ty = t >> 16;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const int lx = (int)(tx * kFastTileW + (wave & 3u) * 8u + (lane & 7u));
@@ -288,7 +310,6 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
         corner[cidx][0] = gx - ex; corner[cidx][1] = gy - ey; corner[cidx][2] = gz - ez;
         if (cidx == 0) { corner[4][0] = ex; corner[4][1] = ey; corner[4][2] = ez; }
     }
-    if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; red[6] = 0x7fffffff; red[7] = -1; red[8] = 0x7fffffff; red[9] = -1; }
     __syncthreads();
     float G[4][3], E[3];
 #pragma unroll
@@ -318,110 +339,140 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
         stage = stage && (pos || neg);
         sgn = neg ? -1 : 1;
     }
+    // the apron copy this tile's bricks stream from: stored with the major axis slowest (PERM), or the order-0 copy
+    const uint8_t *const src_m = PERM ? (ax_m == 2 ? src : (ax_m == 1 ? src_y : src_x)) : src;
     const int nbr0 = P.bnx, nbr1 = P.bny, nbr2 = P.bnz;                // bricks per voxel axis
     const int nbr_m = sel3(ax_m, nbr0, nbr1, nbr2), nbr_a = sel3(ax_a, nbr0, nbr1, nbr2), nbr_b = sel3(ax_b, nbr0, nbr1, nbr2);
     const int ndim_m = sel3(ax_m, P.nx, P.ny, P.nz);
-    // layer (along m) of the cell a position's taps start in: floor(max(f_m - 0.5, 0)) >> 2
-    auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> 2; };
-    {
-        // first / last layer of this ray's prefix in progress coordinates (sgn * layer), prefix length: workgroup extremes
-        // (wavefront reductions first: one lane per wavefront touches the LDS words)
-        int r_first = 0x7fffffff, r_last = -0x7fffffff, r_len = 0;
-        if (rem > 0) {
-            float fx, fy, fz;
-            scaled_here(fx, fy, fz);
-            const int l_first = layer_of(sel3(ax_m, fx, fy, fz));
-            float lx2, ly2, lz2;
-            const float kk = (float)(rem - 1);
-            voxel_float((POW2 ? Qx / Sx : qx) + kk * dsx, (POW2 ? Qy / Sy : qy) + kk * dsy, (POW2 ? Qz / Sz : qz) + kk * dsz, lx2, ly2, lz2);
-            const int l_last = layer_of(sel3(ax_m, lx2, ly2, lz2));
-            r_first = sgn * l_first;
-            r_last = sgn * l_last + 1;                                   // + 1: the closed form may sit one layer short
-            r_len = rem;
-        }
-        r_first = wave_min_i(r_first); r_last = wave_max_i(r_last); r_len = wave_max_i(r_len);
-        if (lane == 0) { atomicMin(&red[0], r_first); atomicMax(&red[1], r_last); atomicMax(&red[2], r_len); }
-    }
-    __syncthreads();
-    const int c_first = uniform_i(red[0]), kmax = uniform_i(red[2]);
-    int c_last = uniform_i(red[1]);
-    const bool any_prefix = kmax > 0;
-    // progress coordinates stay inside the volume
-    c_last = sgn > 0 ? min(c_last, nbr_m - 1) : min(c_last, 0);
-    const int n_phases = any_prefix ? c_last - c_first + 1 : 0;
-    const int L0 = sgn * c_first;                                        // layer of phase 0
+    const int ndim_a = sel3(ax_a, P.nx, P.ny, P.nz), ndim_b = sel3(ax_b, P.nx, P.ny, P.nz);
     // margin between the corner lines and the marched positions: rounding drift of k iterated additions (<= k * 2^-24 * |pos|
     // per axis, |pos| in voxels <= N) + the evaluation error of the lines themselves (eye far away: |E| * 2^-22)
     const float nmax = fmaxf(fmaxf(P.fdim[0], P.fdim[1]), P.fdim[2]);
     const float emax = fmaxf(fmaxf(fabsf(E[0]), fabsf(E[1])), fabsf(E[2]));
-    const float delta = TS_MARGIN + (float)kmax * 1.2e-7f * nmax + emax * 2.4e-7f;
-    // LDS carve-up: [plan | torus tables | ring].  Plan and tables cover only what this tile can touch -- the layers
-    // between one before its first and three past its last (the prefetch distance), and the voxel indices of those
-    // layers' rectangles -- so a 2048^3 volume costs the ring ~1 KiB instead of 20 and oblique footprints get the rest.
-    // The tables hold BYTE offsets, 16-bit for the two minor axes (a slot row / a layer is < 64 KiB), 32-bit for the
-    // major axis (ring base + layer slot + plane); they are addressed through virtual bases (real base - first index).
-    const int ndim_a = sel3(ax_a, P.nx, P.ny, P.nz), ndim_b = sel3(ax_b, P.nx, P.ny, P.nz);
-    const int Llo = max(sgn > 0 ? c_first - 1 : -(c_last + 3), 0), Lhi = min(sgn > 0 ? c_last + 3 : -(c_first - 1), nbr_m - 1);
-    const int n_plan = max(Lhi - Llo + 1, 0);
-    const int plan_bytes = (n_plan * 8 + 15) & ~15;
-    uint2 *plan = reinterpret_cast<uint2 *>(ring) - Llo;                 // plan[L] for Llo <= L <= Lhi
-    if (stage && any_prefix) {
-        int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1, m_low = 0;
-        for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
-            const float c_lo = (float)(4 * L) - 0.5f - delta, c_hi = (float)(4 * L) + 4.5f + delta;
-            float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]), ga = sel3(ax_a, G[c][0], G[c][1], G[c][2]), gb = sel3(ax_b, G[c][0], G[c][1], G[c][2]);
-                const float em = sel3(ax_m, E[0], E[1], E[2]), ea = sel3(ax_a, E[0], E[1], E[2]), eb = sel3(ax_b, E[0], E[1], E[2]);
-                const float t1 = (c_lo - em) / gm, t2 = (c_hi - em) / gm;
-                const float a1 = ea + t1 * ga, a2 = ea + t2 * ga, b1 = eb + t1 * gb, b2 = eb + t2 * gb;
-                amin = fminf(amin, fminf(a1, a2)); amax = fmaxf(amax, fmaxf(a1, a2));
-                bmin = fminf(bmin, fminf(b1, b2)); bmax = fmaxf(bmax, fmaxf(b1, b2));
+
+    // Everything below depends on the layer thickness T = 1 << LSH voxels (4: whole bricks; 2: half bricks, PERM instances
+    // with 16-byte-divisible half bricks only): the plan is made for whole layers first and, when they do not fit the ring
+    // three deep, once more for half layers.
+    int LSH = 2;
+    int slot_b = C::BRICK_BYTES;                                         // bytes per ring slot: a brick or half a brick
+    int c_first = 0, c_last = 0, kmax = 0, n_phases = 0, L0 = 0, Llo = 0, Lhi = -1, plan_bytes = 0;
+    bool any_prefix = false;
+    float delta = 0.0f;
+    uint2 *plan = nullptr;
+    int RA = 1, RB = 1, ia_lo = 0, ib_lo = 0, im_lo = 0, na_e = 0, nb_e = 0, nm_e = 0, taba_bytes = 0, tabb_bytes = 0, head_bytes = 0, slots_avail = 0;
+    bool fits = false;
+    VR_TSLAB_STAT(unsigned st_reason = 0;)
+    for (;;) {
+        const int T = 1 << LSH;
+        const int nlay_m = nbr_m << (2 - LSH);                           // layers along the major axis
+        if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; red[6] = 0x7fffffff; red[7] = -1; red[8] = 0x7fffffff; red[9] = -1; }
+        __syncthreads();
+        // layer (along m) of the cell a position's taps start in: floor(max(f_m - 0.5, 0)) >> LSH
+        auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> LSH; };
+        {
+            // first / last layer of this ray's prefix in progress coordinates (sgn * layer), prefix length: workgroup extremes
+            // (wavefront reductions first: one lane per wavefront touches the LDS words)
+            int r_first = 0x7fffffff, r_last = -0x7fffffff, r_len = 0;
+            if (rem > 0) {
+                float fx, fy, fz;
+                scaled_here(fx, fy, fz);
+                const int l_first = layer_of(sel3(ax_m, fx, fy, fz));
+                float lx2, ly2, lz2;
+                const float kk = (float)(rem - 1);
+                voxel_float((POW2 ? Qx / Sx : qx) + kk * dsx, (POW2 ? Qy / Sy : qy) + kk * dsy, (POW2 ? Qz / Sz : qz) + kk * dsz, lx2, ly2, lz2);
+                const int l_last = layer_of(sel3(ax_m, lx2, ly2, lz2));
+                r_first = sgn * l_first;
+                r_last = sgn * l_last + 1;                               // + 1: the closed form may sit one layer short
+                r_len = rem;
             }
-            // taps: voxels floor(f - 0.5) and + 1 per axis
-            const float big = 1.0e9f;
-            const int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
-            const int hi_a = clampi((int)floorf(fmaxf(fminf(amax + 0.5f + delta, big), -big)) >> 2, 0, nbr_a - 1);
-            const int lo_b = clampi((int)floorf(fmaxf(fminf(bmin - 0.5f - delta, big), -big)) >> 2, 0, nbr_b - 1);
-            const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
-            const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
-            plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
-            m_dda = max(m_dda, dda); m_ddb = max(m_ddb, ddb);            // every planned layer is one some phase reads or prefetches
-            m_loa = min(m_loa, lo_a); m_hia = max(m_hia, hi_a); m_lob = min(m_lob, lo_b); m_hib = max(m_hib, hi_b);
-            if (amin - delta < 1.0f || bmin - delta < 1.0f) m_low = 1;   // some ray comes within a voxel of a low face
+            r_first = wave_min_i(r_first); r_last = wave_max_i(r_last); r_len = wave_max_i(r_len);
+            if (lane == 0) { atomicMin(&red[0], r_first); atomicMax(&red[1], r_last); atomicMax(&red[2], r_len); }
         }
-        m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low);
-        m_loa = wave_min_i(m_loa); m_hia = wave_max_i(m_hia); m_lob = wave_min_i(m_lob); m_hib = wave_max_i(m_hib);
-        if (lane == 0) {
-            atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low);
-            atomicMin(&red[6], m_loa); atomicMax(&red[7], m_hia); atomicMin(&red[8], m_lob); atomicMax(&red[9], m_hib);
+        __syncthreads();
+        c_first = uniform_i(red[0]); kmax = uniform_i(red[2]);
+        c_last = uniform_i(red[1]);
+        any_prefix = kmax > 0;
+        // progress coordinates stay inside the volume
+        c_last = sgn > 0 ? min(c_last, nlay_m - 1) : min(c_last, 0);
+        n_phases = any_prefix ? c_last - c_first + 1 : 0;
+        L0 = sgn * c_first;                                              // layer of phase 0
+        delta = TS_MARGIN + (float)kmax * 1.2e-7f * nmax + emax * 2.4e-7f;
+        // LDS carve-up: [plan | torus tables | ring].  Plan and tables cover only what this tile can touch -- the layers
+        // between one before its first and three past its last (the prefetch distance), and the voxel indices of those
+        // layers' rectangles -- so a 2048^3 volume costs the ring ~1 KiB instead of 20 and oblique footprints get the rest.
+        // The tables hold BYTE offsets, 16-bit for the two minor axes (a slot row / a layer is < 64 KiB), 32-bit for the
+        // major axis (ring base + layer slot + plane); they are addressed through virtual bases (real base - first index).
+        Llo = max(sgn > 0 ? c_first - 1 : -(c_last + 3), 0); Lhi = min(sgn > 0 ? c_last + 3 : -(c_first - 1), nlay_m - 1);
+        const int n_plan = max(Lhi - Llo + 1, 0);
+        plan_bytes = (n_plan * 8 + 15) & ~15;
+        plan = reinterpret_cast<uint2 *>(ring) - Llo;                    // plan[L] for Llo <= L <= Lhi
+        if (stage && any_prefix && plan_bytes <= C::REGION / 2) {
+            int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1, m_low = 0;
+            for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
+                const float c_lo = (float)(T * L) - 0.5f - delta, c_hi = (float)(T * L + T) + 0.5f + delta;
+                float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]), ga = sel3(ax_a, G[c][0], G[c][1], G[c][2]), gb = sel3(ax_b, G[c][0], G[c][1], G[c][2]);
+                    const float em = sel3(ax_m, E[0], E[1], E[2]), ea = sel3(ax_a, E[0], E[1], E[2]), eb = sel3(ax_b, E[0], E[1], E[2]);
+                    const float t1 = (c_lo - em) / gm, t2 = (c_hi - em) / gm;
+                    const float a1 = ea + t1 * ga, a2 = ea + t2 * ga, b1 = eb + t1 * gb, b2 = eb + t2 * gb;
+                    amin = fminf(amin, fminf(a1, a2)); amax = fmaxf(amax, fmaxf(a1, a2));
+                    bmin = fminf(bmin, fminf(b1, b2)); bmax = fmaxf(bmax, fmaxf(b1, b2));
+                }
+                // taps: voxels floor(f - 0.5) and + 1 per axis
+                const float big = 1.0e9f;
+                const int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
+                const int hi_a = clampi((int)floorf(fmaxf(fminf(amax + 0.5f + delta, big), -big)) >> 2, 0, nbr_a - 1);
+                const int lo_b = clampi((int)floorf(fmaxf(fminf(bmin - 0.5f - delta, big), -big)) >> 2, 0, nbr_b - 1);
+                const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
+                const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
+                plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
+                m_dda = max(m_dda, dda); m_ddb = max(m_ddb, ddb);        // every planned layer is one some phase reads or prefetches
+                m_loa = min(m_loa, lo_a); m_hia = max(m_hia, hi_a); m_lob = min(m_lob, lo_b); m_hib = max(m_hib, hi_b);
+                if (amin - delta < 1.0f || bmin - delta < 1.0f) m_low = 1;   // some ray comes within a voxel of a low face
+            }
+            m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low);
+            m_loa = wave_min_i(m_loa); m_hia = wave_max_i(m_hia); m_lob = wave_min_i(m_lob); m_hib = wave_max_i(m_hib);
+            if (lane == 0) {
+                atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low);
+                atomicMin(&red[6], m_loa); atomicMax(&red[7], m_hia); atomicMin(&red[8], m_lob); atomicMax(&red[9], m_hib);
+            }
         }
+        __syncthreads();
+        RA = uniform_i(red[3]) + 1; RB = uniform_i(red[4]) + 1;
+        // voxel index ranges of the tables: [first, last] per role, + 1 entry for the "index + 1" look-ups (at the high face
+        // it repeats the last voxel: the + 1 tap of the last cell is the clamped one)
+        ia_lo = 4 * clampi(uniform_i(red[6]), 0, nbr_a);
+        const int ia_hi = min(4 * clampi(uniform_i(red[7]), -1, nbr_a) + 4, ndim_a);   // (nothing planned: empty)
+        ib_lo = 4 * clampi(uniform_i(red[8]), 0, nbr_b);
+        const int ib_hi = min(4 * clampi(uniform_i(red[9]), -1, nbr_b) + 4, ndim_b);
+        im_lo = T * Llo;
+        const int im_hi = min(T * Lhi + T, ndim_m);
+        na_e = max(ia_hi - ia_lo + 1, 0); nb_e = max(ib_hi - ib_lo + 1, 0); nm_e = max(im_hi - im_lo + 1, 0);
+        taba_bytes = (na_e * 2 + 3) & ~3; tabb_bytes = (nb_e * 2 + 3) & ~3;
+        const int tabm_bytes = nm_e * 4;
+        // (the ring starts on a 256-byte boundary: the 1-KiB DMA pieces then land on whole LDS rows, 1 % on the 1024^3 workload)
+        head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 255) & ~255;
+        slot_b = C::BRICK_BYTES >> (2 - LSH);
+        slots_avail = (C::REGION - head_bytes) / slot_b;
+        const int layer_slots_max = C::MAX_PIECES * TS_THREADS / (slot_b / 16);
+        fits = head_bytes <= C::REGION / 2 && !(RA * RB > layer_slots_max || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * slot_b > 65535);
+        VR_TSLAB_STAT(st_reason = !stage ? 1u : (RA * RB > layer_slots_max ? 2u : (RA * RB * 3 > slots_avail ? 3u : (RA * RB * slot_b > 65535 ? 4u : 0u)));)
+        if (fits || !stage || !any_prefix || !C::HALF_OK || LSH == 1) break;
+        LSH = 1;                                                         // once more with half layers
+        __syncthreads();                                                 // (every thread has read red[] before it is reset)
     }
-    __syncthreads();
-    const int RA = uniform_i(red[3]) + 1, RB = uniform_i(red[4]) + 1;
-    // voxel index ranges of the tables: [first, last] per role, + 1 entry for the "index + 1" look-ups (at the high face
-    // it repeats the last voxel: the + 1 tap of the last cell is the clamped one)
-    const int ia_lo = 4 * clampi(uniform_i(red[6]), 0, nbr_a), ia_hi = min(4 * clampi(uniform_i(red[7]), -1, nbr_a) + 4, ndim_a);   // (nothing planned: empty)
-    const int ib_lo = 4 * clampi(uniform_i(red[8]), 0, nbr_b), ib_hi = min(4 * clampi(uniform_i(red[9]), -1, nbr_b) + 4, ndim_b);
-    const int im_lo = 4 * Llo, im_hi = min(4 * Lhi + 4, ndim_m);
-    const int na_e = max(ia_hi - ia_lo + 1, 0), nb_e = max(ib_hi - ib_lo + 1, 0), nm_e = max(im_hi - im_lo + 1, 0);
-    const int taba_bytes = (na_e * 2 + 3) & ~3, tabb_bytes = (nb_e * 2 + 3) & ~3, tabm_bytes = nm_e * 4;
-    // (the ring starts on a 256-byte boundary: the 1-KiB DMA pieces then land on whole LDS rows, 1 % on the 1024^3 workload)
-    const int head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 255) & ~255;
-    if (head_bytes > C::REGION / 2) stage = false;
+    if (!fits) stage = false;
+    const int T = 1 << LSH;
     uint16_t *tab_a = reinterpret_cast<uint16_t *>(ring + plan_bytes), *tab_b = reinterpret_cast<uint16_t *>(ring + plan_bytes + taba_bytes);
     uint32_t *tab_m = reinterpret_cast<uint32_t *>(ring + plan_bytes + taba_bytes + tabb_bytes);
     uint8_t *const slots = ring + (stage ? head_bytes : 0);             // the torus of brick slots
-    const int slots_avail = (C::REGION - head_bytes) / C::SLOT;
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-    const unsigned st_reason = !stage ? 1u : (RA * RB > C::LAYER_SLOTS_MAX ? 2u : (RA * RB * 3 > slots_avail ? 3u : (RA * RB * C::SLOT > 65535 ? 4u : 0u)));
-#endif
-    if (RA * RB > C::LAYER_SLOTS_MAX || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * C::SLOT > 65535) stage = false;
+    const int CHR = slot_b / 16;                                         // 16-byte chunks per slot
     const int RZ = stage ? min(slots_avail / (RA * RB), 4) : 1;
     const int LA = RZ - 2;                                               // phases of prefetch distance: 1 or 2
-    const uint32_t layer_bytes = (uint32_t)(RA * RB * C::SLOT);
-    const int pieces = (RA * RB * C::CH + TS_THREADS - 1) / TS_THREADS;
+    const uint32_t layer_bytes = (uint32_t)(RA * RB * slot_b);
+    const int pieces = (RA * RB * CHR + TS_THREADS - 1) / TS_THREADS;
     const uint32_t str0 = 1u, str1 = (uint32_t)P.bnx, str2 = (uint32_t)P.bnx * (uint32_t)P.bny;   // brick index strides
     const uint32_t sA = sel3(ax_a, str0, str1, str2), sB = sel3(ax_b, str0, str1, str2), sM = sel3(ax_m, str0, str1, str2);
     // per-lane loader constants of piece q: torus coordinates (ta, tb) of the slot this lane's 16-byte chunk belongs to,
@@ -438,7 +489,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
             plan[L] = e;
         }
         // torus tables: N + 1 entries per axis (the last one repeats voxel N - 1: the + 1 tap of the last cell is the
-        // clamped one): byte offset of the slot of brick (i >> 2) mod R + of the position inside the 5x4x4 apron brick;
+        // clamped one): byte offset of the slot of brick (i >> 2) mod R + of the position inside the 5x4x4 apron brick
+        // (strides 1 / 5 / 20 voxels: by voxel axis x / y / z in the order-0 copy, by role a / b / m in the per-axis copies);
         // the major axis' entries include the ring's LDS base, so a tap address is the plain sum of three entries
         const int na = na_e + nb_e + nm_e;
         for (int e = (int)threadIdx.x; e < na; e += TS_THREADS) {
@@ -448,9 +500,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
             else { role = 2; ii = min(im_lo + e - na_e - nb_e, ndim_m - 1); }
             const int axis = role == 0 ? ax_a : (role == 1 ? ax_b : ax_m);
             const int R = role == 0 ? RA : (role == 1 ? RB : RZ);
-            const uint32_t stride = role == 0 ? (uint32_t)C::SLOT : (role == 1 ? (uint32_t)(RA * C::SLOT) : (uint32_t)(RA * RB * C::SLOT));
-            const uint32_t in = (uint32_t)(ii & 3) * (axis == 0 ? 1u : (axis == 1 ? 5u : 20u)) * (uint32_t)sizeof(VoxelT);
-            const uint32_t off = (uint32_t)((ii >> 2) % R) * stride + in;
+            const uint32_t stride = role == 0 ? (uint32_t)slot_b : (role == 1 ? (uint32_t)(RA * slot_b) : layer_bytes);
+            const int order = PERM ? role : axis;
+            const uint32_t in = (uint32_t)(ii & (role == 2 ? T - 1 : 3)) * (order == 0 ? 1u : (order == 1 ? 5u : 20u)) * (uint32_t)sizeof(VoxelT);
+            const uint32_t off = (uint32_t)((ii >> (role == 2 ? LSH : 2)) % R) * stride + in;
             if (role == 0) tab_a[e] = (uint16_t)off;
             else if (role == 1) tab_b[e - na_e] = (uint16_t)off;
             else tab_m[e - na_e - nb_e] = off + lds_offset_of(slots);
@@ -458,8 +511,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
 #pragma unroll
         for (int q = 0; q < C::MAX_PIECES; q++) {
             const int c = (q * TS_NW + (int)wave) * 64 + (int)lane;
-            const int slot = c / C::CH;
-            ld_part[q] = c - slot * C::CH;
+            const int slot = CHR == 5 ? c / 5 : (CHR == 10 ? c / 10 : c / CHR);
+            ld_part[q] = c - slot * CHR;
             ld_tb[q] = slot / RA;
             ld_ta[q] = slot - ld_tb[q] * RA;
             ld_ok[q] = slot < RA * RB && q < pieces;
@@ -477,7 +530,9 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
         const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
         const int dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u), la = (int)((ey >> 16) & 255u), lb = (int)(ey >> 24);
         const int lz = L % RZ;
-        const uint32_t layer_idx = (uint32_t)L * sM;
+        // brick layer and, for half layers, which half of the brick (its first or last two planes along m: 40 contiguous voxels)
+        const uint32_t layer_idx = (uint32_t)(L >> (2 - LSH)) * sM;
+        const uint32_t half_off = LSH == 1 ? (uint32_t)(L & 1) * (uint32_t)(C::BRICK_BYTES / 2) : 0u;
         int n = 0;
 #pragma unroll
         for (int q = 0; q < C::MAX_PIECES; q++) {
@@ -489,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
             if (__any(ok ? 1 : 0)) {
                 if (ok) {
                     const uint32_t brick = __umul24((uint32_t)(lo_a + oa), sA) + __umul24((uint32_t)(lo_b + ob), sB) + layer_idx;
-                    const uint8_t *g = src + (uint64_t)brick * (uint64_t)C::SLOT + (uint64_t)(ld_part[q] * 16);
+                    const uint8_t *g = src_m + (uint64_t)brick * (uint64_t)C::BRICK_BYTES + (uint64_t)(half_off + (uint32_t)(ld_part[q] * 16));
                     glds16(g, ring_base + (uint32_t)lz * layer_bytes + (uint32_t)(q * TS_NW + (int)wave) * 1024u);
                 }
                 n++;
@@ -498,21 +553,21 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
         return n;
     };
 
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-    unsigned st_samples = 0, st_iters = 0;
-    const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();
-#endif
+    VR_TSLAB_STAT(unsigned st_samples = 0, st_iters = 0; const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();)
     // The staged march, compiled once per major axis M (the tables of the minor axes are 16-bit, M's 32-bit; the layer of
-    // a sample is its M index >> 2)
+    // a sample is its M index >> LSH).  PA = the voxel axis along which one LDS address yields a pair of taps (the apron
+    // axis of the copy the bricks came from): x, or the first minor axis in the per-axis copies (y when M is x).
     auto staged_march = [&](auto m_tag) {
         constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0;          // minor axes: A and the other one
+        constexpr int PA = PERM ? A : 0, O1 = PA == 0 ? 1 : 0, O2 = 2;         // the other two voxel axes, in x-y-z order
         // ---- prologue: the layers phases 0 .. LA-1 read
         if (sgn > 0) { for (int l = 0; l <= LA; l++) (void)issue_layer(L0 + l); }
         else { for (int l = 1; l >= 1 - LA; l--) (void)issue_layer(L0 + l); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // prepared sample (the one at the current position): tap BYTE addresses of the (y0,z0), (y1,z0), (y0,z1), (y1,z1)
-        // corner pairs, the three weights, its layer along m.  prepare() runs once per sample -- right after the advance --
+        // prepared sample (the one at the current position): tap BYTE addresses of the four corner pairs -- (O1, O2) = (0,0),
+        // (1,0), (0,1), (1,1), i.e. (y0,z0), (y1,z0), (y0,z1), (y1,z1) when the pairs lie along x --, the three weights, its
+        // layer along m.  prepare() runs once per sample -- right after the advance --
         // so a ray that waits for its layer's phase keeps the values across the barrier instead of recomputing them.
         uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
         float wx = 0.0f, wy = 0.0f, wz = 0.0f;
@@ -524,10 +579,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
             constexpr int AX = decltype(ax_tag)::value;
             if (AX == M) {
                 VR_LDS_AS const uint32_t *e = reinterpret_cast<VR_LDS_AS const uint32_t *>((size_t)(tab_m_b + 4u * (uint32_t)idx));
-                o0 = e[0]; if (AX != 0) o1 = e[1];
+                o0 = e[0]; if (AX != PA) o1 = e[1];
             } else {
                 VR_LDS_AS const uint16_t *e = reinterpret_cast<VR_LDS_AS const uint16_t *>((size_t)((AX == A ? tab_a_b : tab_b_b) + 2u * (uint32_t)idx));
-                o0 = e[0]; if (AX != 0) o1 = e[1];
+                o0 = e[0]; if (AX != PA) o1 = e[1];
             }
         };
         // (the weights are derived from ux, uy, uz by the caller AFTER the previous sample has used its own: no copies)
@@ -542,19 +597,21 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
             if (CLAMP) { ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f); }
             else { ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f; }
             const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor: u >= 0
-            lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> 2;
-            uint32_t x0, xunused = 0, y0, y1, z0, z1;
-            look(std::integral_constant<int, 0>{}, i0, x0, xunused);     // the x1 taps are the x0 taps' next elements (apron)
-            look(std::integral_constant<int, 1>{}, j0, y0, y1);
-            look(std::integral_constant<int, 2>{}, k0, z0, z1);
-            const uint32_t xz0 = x0 + z0, xz1 = x0 + z1;
-            a00 = xz0 + y0; a10 = xz0 + y1; a01 = xz1 + y0; a11 = xz1 + y1;
+            lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> LSH;
+            uint32_t p0, punused = 0, q0, q1, z0, z1;
+            look(std::integral_constant<int, PA>{}, PA == 0 ? i0 : j0, p0, punused);   // the second taps of the pairs are the first ones' next elements (apron)
+            look(std::integral_constant<int, O1>{}, O1 == 0 ? i0 : j0, q0, q1);
+            look(std::integral_constant<int, O2>{}, k0, z0, z1);
+            const uint32_t pz0 = p0 + z0, pz1 = p0 + z1;
+            a00 = pz0 + q0; a10 = pz0 + q1; a01 = pz1 + q0; a11 = pz1 + q1;
         };
         auto weights = [&]() { wx = __builtin_amdgcn_fractf(ux); wy = __builtin_amdgcn_fractf(uy); wz = __builtin_amdgcn_fractf(uz); };   // == u - floor(u), exact: u >= 0
         prepare(std::true_type{}); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
         const bool ahead_ok = LA >= 2;
         const bool clamp_tile = uniform_i(red[5]) != 0;
+        // voxels a step can advance along any axis (box units -> voxels: at most step * largest dimension / smallest extent)
+        const int clamp_L = 2 + (int)(P.step * nmax / fminf(fminf(P.ext[0], P.ext[1]), P.ext[2])) / T;
         float takenf = 0.0f;
         const float limitf = (float)rem;
         for (int p = 0; p < n_phases; p++) {
@@ -581,19 +638,13 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
                     const bool here = alive && lay == L;
                     if (!__any(here ? 1 : 0)) break;
                     const bool valid = here || (alive && lay == Lnext && ahead_ok);
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)
-                    st_iters++;
-                    st_samples += valid ? 1 : 0;
-#endif
+                    VR_TSLAB_STAT(st_iters++; st_samples += valid ? 1 : 0;)
                     const float vf = valid ? 1.0f : 0.0f;
                     VR_LDS_AS const VoxelT *p00 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a00), *p10 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a10);
                     VR_LDS_AS const VoxelT *p01 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a01), *p11 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a11);
-#if defined(VR_EXPERIMENTS) && defined(VR_X_NOTAPS)
-                    const uint32_t v000 = a00 & 255u, v100 = a10 & 255u, v010 = a01 & 255u, v110 = a11 & 255u, v001 = (a00 >> 8) & 255u, v101 = (a10 >> 8) & 255u, v011 = (a01 >> 8) & 255u, v111 = (a11 >> 8) & 255u;
-                    (void)p00; (void)p10; (void)p01; (void)p11;
-#else
-                    const uint32_t v000 = p00[0], v100 = p00[1], v010 = p10[0], v110 = p10[1], v001 = p01[0], v101 = p01[1], v011 = p11[0], v111 = p11[1];
-#endif
+                    // pairs along x: p00 = (y0, z0) ...; pairs along y (PA == 1): p00 = (x0, z0), p10 = (x1, z0), p01 = (x0, z1), p11 = (x1, z1)
+                    const uint32_t v000 = p00[0], v100 = PA == 0 ? p00[1] : p10[0], v010 = PA == 0 ? p10[0] : p00[1], v110 = p10[1];
+                    const uint32_t v001 = p01[0], v101 = PA == 0 ? p01[1] : p11[0], v011 = PA == 0 ? p11[0] : p01[1], v111 = p11[1];
                     // the next sample's position and table look-ups travel with the taps (a lane that did not advance prepares
                     // the same sample again: same values)
                     if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
@@ -636,22 +687,17 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
                     weights();                                               // of the sample just prepared
                 }
             };
-            // (L <= 2: with a ray running one layer ahead the sample prepared next may lie two layers on)
-            if (clamp_tile || L <= 2) phase_samples(std::true_type{});
+            // (L <= clamp_L: with a ray running one layer ahead the sample prepared next may lie two layers on, and a step's
+            // worth of voxels beyond that)
+            if (clamp_tile || L <= clamp_L) phase_samples(std::true_type{});
             else phase_samples(std::false_type{});
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
-#if !(defined(VR_EXPERIMENTS) && defined(VR_X_NOWAIT))
             (void)n_new;
             slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
-#endif
             // every 8th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
-#if defined(VR_EXPERIMENTS) && defined(VR_X_NOBAR)
-            if ((p & 31) == 31) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
-#else
             if ((p & 7) == 7) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
             else __syncthreads();
-#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no DMA may outlive the workgroup's LDS
         i += (int)takenf;
@@ -764,53 +810,42 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB>::WAVES_
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
-#if defined(VR_EXPERIMENTS) && defined(VR_X_STATS)      // per-tile statistics instead of the fetch count of the tile's first pixel
-    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | (st_reason << 1) | ((unsigned)RZ << 4) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
+    VR_TSLAB_STAT(      // per-tile statistics instead of the fetch counts of the tile's first pixels (tools/tslab_stats.py)
+    if (spp && threadIdx.x == 0) { spp[pix] = 0x80000000u | (stage ? 1u : 0u) | (st_reason << 1) | ((unsigned)RZ << 4) | ((unsigned)(LSH == 1) << 7) | ((unsigned)min(RA * RB, 255) << 8) | ((unsigned)min(n_phases, 4095) << 16); return; }
     // shader-clock ticks and 100 MHz wall ticks of the staged loop (threads 1, 2), iterations and samples of wavefront 0 (threads 3, 4)
     if (spp && threadIdx.x == 1) { spp[pix] = (uint32_t)(clock64() - st_clk0); return; }
     if (spp && threadIdx.x == 2) { spp[pix] = (uint32_t)(wall_clock64() - st_wall0); return; }
     if (spp && threadIdx.x == 3) { spp[pix] = st_iters; return; }
     if (spp && threadIdx.x == 4) { spp[pix] = st_samples; return; }
-    if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; }   // set-up: ray, head, plan, tables
-#endif
+    if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; })   // set-up: ray, head, plan, tables
     if (spp) spp[pix] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE>
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 4: u16 (below)
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
 {
-    // L.tri_slab: 1 = 32x16 tiles, two workgroups per CU; 2 = the same with staging switched off; 3 = 32x16 tiles on the
-    // whole LDS of a CU; 4 = 32x32 tiles (16 wavefronts) on the whole LDS, from the 32-row tile table
-    if constexpr (sizeof(VoxelT) == 2) {                                 // (8-bit layers fit the 80-KiB ring at every pose measured)
-        if (L.tri_slab == 3) {
-            hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 8, 160>), dim3(L.tile_table_blocks), dim3(512), 0, st, P,
-                               (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table, 0);
-            return hipGetLastError();
-        }
-        if (L.tri_slab == 4 && L.tile_table32 != nullptr) {
-            hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 16, 160>), dim3(L.tile_table32_blocks), dim3(1024), 0, st, P,
-                               (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table32, 0);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, 8, 80>), dim3(L.tile_table_blocks), dim3(512), 0, st, P,
-                       (const VoxelT *)vol, (const uint8_t *)L.apron, tf, fb, spp, L.tile_table, L.tri_slab == 2 ? 1 : 0);
+    const uint32_t *table = NW == 16 ? L.tile_table32 : L.tile_table;
+    const uint32_t blocks = NW == 16 ? L.tile_table32_blocks : L.tile_table_blocks;
+    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM>), dim3(blocks), dim3(64 * NW), 0, st, P,
+                       (const VoxelT *)vol, (const uint8_t *)L.apron, (const uint8_t *)L.apron_y, (const uint8_t *)L.apron_x, tf, fb, spp, table,
+                       L.tri_slab == 2 ? 1 : 0);
     return hipGetLastError();
 }
 
-template <typename VoxelT, int VIEW, int MODE>
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int VIEW, int MODE>
 static hipError_t dispatch_tslab3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                   uint32_t *spp, hipStream_t st)
 {
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-    if (L.divmode_tc == DIV_CERT) return launch_tslab<VoxelT, DIV_CERT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
-    if (pow2) return launch_tslab<VoxelT, DIV_UNIT, VIEW, true, MODE>(P, L, vol, tf, fb, spp, st);
-    return launch_tslab<VoxelT, DIV_UNIT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+    if (L.divmode_tc == DIV_CERT) return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_CERT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+    if (pow2) return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_UNIT, VIEW, true, MODE>(P, L, vol, tf, fb, spp, st);
+    return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_UNIT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
 }
 
-template <typename VoxelT>
+template <typename VoxelT, int NW, int LDSKB, bool PERM>
 static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                  uint32_t *spp, hipStream_t st)
 {
@@ -818,10 +853,10 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
     const int mode = (L.mip ? 1 : 0) + (P.tf_len > 1 ? 2 : 0);
 #define VR_TSLAB_M(VW)                                                                                         \
     switch (mode) {                                                                                            \
-    case 0: return dispatch_tslab3<VoxelT, VW, 0>(P, L, vol, tf, fb, spp, st);                                 \
-    case 1: return dispatch_tslab3<VoxelT, VW, 1>(P, L, vol, tf, fb, spp, st);                                 \
-    case 2: return dispatch_tslab3<VoxelT, VW, 2>(P, L, vol, tf, fb, spp, st);                                 \
-    default: return dispatch_tslab3<VoxelT, VW, 3>(P, L, vol, tf, fb, spp, st);                                \
+    case 0: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 0>(P, L, vol, tf, fb, spp, st);                \
+    case 1: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 1>(P, L, vol, tf, fb, spp, st);                \
+    case 2: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 2>(P, L, vol, tf, fb, spp, st);                \
+    default: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 3>(P, L, vol, tf, fb, spp, st);               \
     }
     if (view == 0) { VR_TSLAB_M(0) }
     if (view == 1) { VR_TSLAB_M(1) }
@@ -829,23 +864,42 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
 #undef VR_TSLAB_M
 }
 
-// translation units: 0 = u8 volumes, 1 = u16 volumes; -1 = both
+#define VR_TSLAB_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, hipStream_t st
+// 16-bit volumes, by workgroup shape (LaunchConfig::tri_slab; vr_set_kernel_variant 6 .. 10):
+//   tri_slab 1 (2 = staging off): 32x16 tiles, 80 KiB, order-0 copy, whole layers
+//   tri_slab 3: the same with the per-axis copies, layer thickness per tile (half layers where whole ones do not fit)
+//   tri_slab 4: 32x32 tiles, 16 wavefronts, a CU's whole LDS, per-axis copies, thickness per tile
+//   tri_slab 5: 32x16 tiles on a CU's whole LDS, per-axis copies, thickness per tile
+// (round 4 also measured the whole-LDS shapes with whole layers only: 32x16 tiles 1.96-2.13 ms over the orbit poses, 32x32
+// tiles 1.64-3.6 ms -- behind the half-layer shapes at every pose, not kept)
+hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS);
+
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
 #endif
 #if VR_TSLAB_TU == 0 || VR_TSLAB_TU == -1
-hipError_t launch_raymarch_slab_tri_u8(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                       uint32_t *spp, hipStream_t st)
-{
-    return dispatch_tslab<uint8_t>(P, L, vol, tf, fb, spp, st);
-}
+hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st); }
 #endif
 #if VR_TSLAB_TU == 1 || VR_TSLAB_TU == -1
-hipError_t launch_raymarch_slab_tri_u16(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                                        uint32_t *spp, hipStream_t st)
+hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
 {
-    return dispatch_tslab<uint16_t>(P, L, vol, tf, fb, spp, st);
+    const bool perm_ok = L.apron_y != nullptr && L.apron_x != nullptr, t32 = L.tile_table32 != nullptr;
+    if (L.tri_slab == 3 && perm_ok) return launch_tslab_u16_half(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 4 && perm_ok && t32) return launch_tslab_u16_half16(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 5 && perm_ok) return launch_tslab_u16_halfwide(P, L, vol, tf, fb, spp, st);
+    return dispatch_tslab<uint16_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
+#endif
+#if VR_TSLAB_TU == 2 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 80, true>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 3 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 16, 160, true>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 4 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 160, true>(P, L, vol, tf, fb, spp, st); }
 #endif
 
 }  // namespace vr

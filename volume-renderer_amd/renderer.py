@@ -118,6 +118,7 @@ def load_library() -> C.CDLL:
         "vr_set_skip_empty": (i32, [h, i32]),
         "vr_set_kernel_variant": (i32, [h, i32]),
         "vr_set_autotune": (i32, [h, i32]),
+        "vr_get_launch_choice": (i32, [h]),
         "vr_set_pack12": (i32, [h, i32]),
         "vr_get_pack12_bytes": (i32, [h, C.POINTER(C.c_size_t)]),
         "vr_set_trilinear_copy": (i32, [h, i32]),
@@ -489,6 +490,11 @@ class RendererCore:
 
     def setSkipEmpty(self, on):
         self._check(self._lib.vr_set_skip_empty(self._h, int(bool(on))))
+
+    @property
+    def last_launch_choice(self):
+        """candidate bits of the last launch: 1 relay, 2 pipelined loop, 4 short batches, staged-trilinear shape << 3"""
+        return int(self._lib.vr_get_launch_choice(self._h))
 
     def setKernelVariant(self, variant):
         self._check(self._lib.vr_set_kernel_variant(self._h, variant))
