@@ -422,10 +422,16 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": load_traffic(args, world),
+                "traffic": load_traffic(args, world, r.last_kernel_name),
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
+        if world == 1:
+            # the bound that binds: VALU issue next to HBM (a committed PMC pass of this command x the hot loops' measured
+            # cost per instruction); `roofline` above stays the metric's own HBM figure
+            result["roofline_valu"] = valu_roofline(headline_key(args), r.last_kernel_name, kernel_ms)
+            fv = (result["roofline_valu"] or {}).get("frac")
+            result["binding_bound"] = "valu" if fv is not None and fv > result["roofline"]["frac"] else "hbm"
         if world == 1:
             # the box's own achievable HBM read rate (streaming read of the resident volume),
             # measured after the timed region ("confirm the peak on the box")
@@ -483,24 +489,21 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def load_traffic(args, world):
+def headline_key(args):
+    """key of this command in profiles/traffic.json / valu.json, or None for commands that have no committed PMC pass"""
+    if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12:
+        return None
+    return f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
+
+
+def load_traffic(args, world, kernel):
     """HBM bytes per launch from the committed PMC profile of this same command
     (profiles/traffic.json, written by tools/pmc_traffic.py), or null -- also null when the
-    kernels have changed since the counters were collected (source hash mismatch)."""
-    p = ROOT / "profiles" / "traffic.json"
-    if world != 1 or not p.exists():
+    kernels have changed since the counters were collected (source hash mismatch) or the
+    counters belong to another kernel than the one this run launched."""
+    if world != 1:
         return None
-    try:
-        d = json.loads(p.read_text())
-        if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12:
-            return None
-        key = f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
-        entry = d.get(key)
-        if isinstance(entry, dict):
-            return entry.get("bytes") if entry.get("kernel_source_hash") == kernel_source_hash() else None
-        return None          # legacy entry without a source hash: cannot be attributed to these kernels
-    except Exception:
-        return None
+    return traffic_entry(headline_key(args), kernel)
 
 
 def cpu_baseline(args, r, frame, gpu_msamples):
@@ -578,17 +581,61 @@ def cpu_baseline(args, r, frame, gpu_msamples):
     }
 
 
-def traffic_entry(key):
-    """PMC traffic (HBM bytes per launch) of one extras configuration from profiles/traffic.json, only when it was
-    collected on these kernel sources"""
+def traffic_entry(key, kernel):
+    """PMC traffic (HBM bytes per launch) of one configuration from profiles/traffic.json, only when it was collected on
+    these kernel sources AND for the kernel this run launched (round 3 quoted another kernel's counters)"""
     p = ROOT / "profiles" / "traffic.json"
     try:
-        entry = json.loads(p.read_text()).get(key)
-        if isinstance(entry, dict) and entry.get("kernel_source_hash") == kernel_source_hash():
+        entry = json.loads(p.read_text()).get(key) if key else None
+        if isinstance(entry, dict) and entry.get("kernel_source_hash") == kernel_source_hash() and entry.get("kernel") == kernel:
             return entry.get("bytes")
     except Exception:
         pass
     return None
+
+
+VALU_FAMILY = {"raymarch_slab_tri_kernel": "raymarch_tslab_kernel"}
+
+
+def valu_roofline(key, kernel, kernel_ms):
+    """VALU-issue fraction of one configuration: measured wave-instructions (profiles/valu.json: SQ_INSTS_VALU and the
+    launch's shader cycles, tools/pmc_valu.py) x the cost per instruction of the kernel family's hot loops
+    (profiles/valu_cpi.json, tools/valu_cpi.py) / (1024 SIMDs x cycles).  The cycles are the PMC pass's own
+    (GRBM_GUI_ACTIVE / 8), scaled to this run's kernel time at the same clock.  None when there is no committed pass
+    for these kernel sources and this kernel."""
+    try:
+        v = json.loads((ROOT / "profiles" / "valu.json").read_text()).get(key) if key else None
+        cpi_all = json.loads((ROOT / "profiles" / "valu_cpi.json").read_text())
+        if not isinstance(v, dict) or v.get("kernel") != kernel or v.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        fam = VALU_FAMILY.get(kernel, kernel)
+        if fam == "raymarch_tslab_kernel" and ", true>" in v.get("instance", ""):
+            fam = "raymarch_tslab_kernel_half"
+        cpi = cpi_all["families"][fam]["cpi"]
+        issue_cycles = v["valu_wave_insts"] * cpi / 1024.0
+        return {"bound": "valu", "wave_insts": v["valu_wave_insts"], "cycles_per_inst": cpi, "issue_cycles_per_simd": round(issue_cycles, 1),
+                "shader_cycles": v["shader_cycles"], "frac": round(issue_cycles / v["shader_cycles"], 4), "kernel": kernel,
+                "unit": "VALU issue cycles / shader cycles (PMC pass: profiles/valu.json; costs: profiles/valu_cpi.json)"}
+    except Exception:
+        return None
+
+
+def sparse_row_parity(r, rows, **oracle_kw):
+    """the rows `rows` of the frame r renders now against the CPU oracle (test infrastructure: the checker).  Returns
+    (bit_exact, max_abs_diff)."""
+    import numpy as np
+    import oracle
+
+    r.render()
+    got = r.readPixels()
+    H, W = got.shape[0], got.shape[1]
+    vol = oracle_kw.pop("vol")
+    p = oracle.OracleParams(W, H, cam=r.getCameraBlock(), threads=min(os.cpu_count() or 1, 16), **oracle_kw)
+    want = np.zeros((H, W, 4), dtype=np.float32)
+    for y in rows:
+        p.row_begin, p.row_end = int(y), int(y) + 1
+        oracle.render(vol, p, out=want)
+    return bool(np.array_equal(got[rows].view(np.uint32), want[rows].view(np.uint32))), float(np.max(np.abs(got[rows] - want[rows])))
 
 
 def config_extras(device):
@@ -607,8 +654,9 @@ def config_extras(device):
     R = vra.renderer
     out = {}
 
-    def timed(r, name, b, W, H, steps, key=None):
+    def timed(r, name, b, W, H, steps, key=None, **okw):
         s = r.countSamples()
+        ok, diff = sparse_row_parity(r, [H // 4 + 3, H // 2, (3 * H) // 4 - 5], **okw)      # three rows through the volume, against the oracle
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.08:
             for _ in range(4):
@@ -621,7 +669,11 @@ def config_extras(device):
         gbps = (s * b + W * H * 16) / (ms * 1e-3) / 1e9
         out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
                      "mpixels_per_s": round(W * H / ms / 1e3, 1), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4),
-                     "kernel": r.last_kernel_name, "traffic": traffic_entry(key or name)}
+                     "kernel": r.last_kernel_name, "traffic": traffic_entry(key or name, r.last_kernel_name),
+                     "roofline_valu": valu_roofline(key or name, r.last_kernel_name, ms),
+                     "parity_bit_exact_on_sample": ok, "parity_max_abs_diff_on_sample": diff}
+        fv = (out[name]["roofline_valu"] or {}).get("frac")
+        out[name]["bound"] = "valu" if fv is not None and fv > out[name]["roofline_frac"] else "hbm"
 
     def renderer(W, H):
         r = vra.RendererCore(device)
@@ -635,10 +687,11 @@ def config_extras(device):
         else:
             r.generateSynthetic(R.SYNTH_SPHERE_U8, (256, 256, 256), 1, 112)
         r.setWindow(0, 255); r.setAlpha(1.0)
-        timed(r, "cfg1_shape", 1, 1280, 720, 40)
+        vol = r.readVolume()
+        timed(r, "cfg1_shape", 1, 1280, 720, 40, vol=vol, alpha_scale=1.0, min_val=0, max_val=255)
         out["cfg1_shape"]["data"] = Path(f).name if f else "synthetic sphere 256^3 u8"
         r.setFilter(R.FILTER_TRILINEAR)                      # the north-star's filter on the same configuration
-        timed(r, "cfg1_shape_trilinear", 1, 1280, 720, 40)
+        timed(r, "cfg1_shape_trilinear", 1, 1280, 720, 40, vol=vol, alpha_scale=1.0, min_val=0, max_val=255, filter=1)
     with renderer(1920, 1080) as r:
         f = os.environ.get("VR_DATA_HEAD")
         if f:
@@ -649,21 +702,24 @@ def config_extras(device):
             r.generateSynthetic(R.SYNTH_NOISE_BALL, (512, 512, 452), 2, 0x9E3779B9)
             r.setWindow(1000, 5095)
         r.setAlpha(0.05)
-        timed(r, "cfg2_shape_ert_window", 2, 1920, 1080, 40)
+        vol = r.readVolume()
+        lo, hi = r.window
+        timed(r, "cfg2_shape_ert_window", 2, 1920, 1080, 40, vol=vol, alpha_scale=0.05, min_val=lo, max_val=hi)
         out["cfg2_shape_ert_window"]["data"] = Path(f).name if f else "synthetic noise ball 512x512x452 u16"
         r.setFilter(R.FILTER_TRILINEAR)
-        timed(r, "cfg2_shape_ert_window_trilinear", 2, 1920, 1080, 40)
+        timed(r, "cfg2_shape_ert_window_trilinear", 2, 1920, 1080, 40, vol=vol, alpha_scale=0.05, min_val=lo, max_val=hi, filter=1)
     with renderer(3840, 2160) as r:
         r.generateSynthetic(R.SYNTH_NOISE_BALL, (2048, 2048, 2048), 1, 0x9E3779B9)
         r.setWindow(8, 255); r.setAlpha(0.004)
-        timed(r, "cfg4_grey", 1, 3840, 2160, 10)
+        vol = r.readVolume()                                 # 8 GiB over PCIe once, for the oracle's rows
+        timed(r, "cfg4_grey", 1, 3840, 2160, 10, vol=vol, alpha_scale=0.004, min_val=8, max_val=255)
         r.setFilter(R.FILTER_TRILINEAR)                      # 10 GiB apron copy next to the 8 GiB volume; the LDS-staged kernel (64-bit DMA addresses)
-        timed(r, "cfg4_grey_trilinear", 1, 3840, 2160, 5)
+        timed(r, "cfg4_grey_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, filter=1)
         out["cfg4_grey_trilinear"]["apron_copy_bytes"] = r.trilinearCopyBytes()
         r.setFilter(R.FILTER_NEAREST)
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
         r.setSkipEmpty(True)
-        timed(r, "cfg4_tf_skip", 1, 3840, 2160, 10)
+        timed(r, "cfg4_tf_skip", 1, 3840, 2160, 10, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, tf_rgba=r.getTransferLut())
     return out
 
 
@@ -678,9 +734,19 @@ def extras(args, r, local, stream, b, W, H):
     R = vra.renderer
     out = {}
 
-    def timed(name, steps=20):
+    vol_host = [None]
+
+    def timed(name, steps=20, **okw):
         r.setFramebufferExternal(0); r.setFramebufferCompact(False)
         s = r.countSamples()
+        if vol_host[0] is None:
+            vol_host[0] = r.readVolume()
+        vmax = 4095 if b == 2 else 255
+        win = tuple(args.window) if args.window else (0, vmax)
+        kw = dict(vol=vol_host[0], alpha_scale=args.alpha, min_val=win[0], max_val=win[1], filter=1 if args.filter == "trilinear" else 0,
+                  tf_rgba=r.getTransferLut() if args.tf else None)
+        kw.update(okw)
+        ok, diff = sparse_row_parity(r, [H // 4 + 3, H // 2, (3 * H) // 4 - 5], **kw)
         r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.08:      # back to sustained clocks (the CPU baseline left the GPU idle)
@@ -697,7 +763,11 @@ def extras(args, r, local, stream, b, W, H):
         gbps = (s * b + W * H * 16) / (ms * 1e-3) / 1e9
         out[name] = {"kernel_ms": round(ms, 4), "samples": s, "msamples_per_s": round(s / ms / 1e3, 1),
                      "mpixels_per_s": round(W * H / ms / 1e3, 1), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4),
-                     "kernel": r.last_kernel_name, "traffic": traffic_entry(name)}
+                     "kernel": r.last_kernel_name, "traffic": traffic_entry(name, r.last_kernel_name),
+                     "roofline_valu": valu_roofline(name, r.last_kernel_name, ms),
+                     "parity_bit_exact_on_sample": ok, "parity_max_abs_diff_on_sample": diff}
+        fv = (out[name]["roofline_valu"] or {}).get("frac")
+        out[name]["bound"] = "valu" if fv is not None and fv > out[name]["roofline_frac"] else "hbm"
 
     if args.extras:
         # PCIe-inclusive: kernel + D2H of the finished RGBA32F frame (vr_read_pixels), for DESIGN.md
@@ -727,11 +797,11 @@ def extras(args, r, local, stream, b, W, H):
         timed("headline_without_pack12")       # general 16-bit data (voxels above 4095 somewhere)
         r.setPack12(True)
     r.setAlpha(1.0)
-    timed("shallow_alpha1_ert")
+    timed("shallow_alpha1_ert", alpha_scale=1.0)
     r.setAlpha(args.alpha)
     if args.filter == "nearest":
         r.setFilter(R.FILTER_TRILINEAR)
-        timed("trilinear_deep", steps=10)
+        timed("trilinear_deep", steps=10, filter=1)
         out["trilinear_deep"]["apron_copy_bytes"] = r.trilinearCopyBytes()      # TRILINEAR's own copy of the volume (vr_set_trilinear_copy)
         r.setFilter(R.FILTER_NEAREST)
     if args.pose == "default":
@@ -739,7 +809,7 @@ def extras(args, r, local, stream, b, W, H):
         timed("offaxis_deep", steps=10)
         if args.filter == "nearest":
             r.setFilter(R.FILTER_TRILINEAR)
-            timed("trilinear_offaxis_deep", steps=10)      # oblique view: the 16-bit volume's brick layers do not fit LDS three deep
+            timed("trilinear_offaxis_deep", steps=10, filter=1)      # oblique view: half layers of the staged kernel (round 3: the batched kernel)
             r.setFilter(R.FILTER_NEAREST)
         r.resetCamera()
     if args.extras:

@@ -1,18 +1,20 @@
 #!/bin/bash
-# HBM traffic (PMC: 2 * FETCH_SIZE + WRITE_SIZE, separate passes) of the configurations bench.py reports under `extras`,
-# written to profiles/traffic.json under the extras' names (keyed by the kernel-source hash like the headline's entry).
+# HBM traffic (PMC: 2 * FETCH_SIZE + WRITE_SIZE, separate passes) and VALU wave-instructions / shader cycles (SQ_INSTS_VALU,
+# GRBM_GUI_ACTIVE) of the configurations bench.py reports under `extras`, written to profiles/traffic.json / profiles/valu.json under
+# the extras' names (with the kernel each figure belongs to and the kernel-source hash, like the headline's entries).
 #   gpurun --timeout 1800 -- tools/extras_traffic.sh
 set -u
 cd "$(dirname "$0")/.."; REPO=$PWD; export TMPDIR=/tmp
 run() {   # key, bench args...
   KEY=$1; shift
   OUT=$REPO/gpurun_out/traffic_$KEY; mkdir -p "$OUT"
-  CMD="python $REPO/bench.py --steps 6 --warmup 2 --clock-ramp-frames 20 --no-cpu-baseline --no-extras $*"
-  (cd /tmp; for C in FETCH_SIZE WRITE_SIZE; do
+  CMD="python $REPO/bench.py --steps 6 --warmup 2 --clock-ramp-frames 40 --no-cpu-baseline --no-extras $*"
+  (cd /tmp; for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
      timeout -k 5 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- $CMD > "$OUT/$C.log" 2>&1
    done)
   python tools/summarize_profile.py "$OUT" "$KEY" > "$OUT/summary.txt" 2>&1
-  python tools/pmc_traffic.py "$OUT/summary.txt" "$KEY"
+  python tools/pmc_traffic.py "$OUT" "$KEY"
+  python tools/pmc_valu.py "$OUT" "$KEY"
 }
 run cfg1_shape --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255
 run cfg2_shape_ert_window --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095

@@ -48,7 +48,7 @@ def kernel_from_logs(out):
 def per_kernel(out, counter):
     """{full kernel name: [values]} of one counter, from the pass that collected it"""
     acc = defaultdict(list)
-    for f in glob.glob(os.path.join(out, f"pmc_*{counter}*", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == counter:

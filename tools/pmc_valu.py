@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""VALU-issue figure of the kernel a bench line names, from the PMC passes of a tools/profile.sh / tools/extras_traffic.sh
+output directory -> profiles/valu.json (bench.py: `roofline_valu`).
+
+    wave-instructions = SQ_INSTS_VALU (per launch, summed over the chip)
+    shader cycles     = GRBM_GUI_ACTIVE / 8   (rocprofv3 sums the counter over the eight XCDs: profiles/r03_headline_summary.txt,
+                        8.71 M for a 0.46-ms launch = 1.09 M cycles = 2.36 GHz)
+    fraction          = wave-instructions x cpi / (1024 SIMDs x shader cycles), cpi per kernel family from the ISA of its hot
+                        loops and the measured per-instruction costs (tools/valu_cpi.py -> profiles/valu_cpi.json)
+
+Kernel selection as in tools/pmc_traffic.py: grouped by the full kernel name, the family the run's own JSON line names, the
+most-launched instance, at least half of the run's ray-march launches.
+usage: tools/pmc_valu.py <profile output dir> <key> [kernel family]"""
+import json
+import re
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from pmc_traffic import ALIAS, kernel_from_logs, per_kernel
+
+
+def main():
+    out, key = sys.argv[1], sys.argv[2]
+    family = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
+    if not family:
+        sys.exit(f"{key}: no kernel family given and no bench JSON line in {out}/*.log")
+    symbol = ALIAS.get(family, family)
+    vals, picked = {}, None
+    for counter in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
+        acc = per_kernel(out, counter)
+        march = {k: v for k, v in acc.items() if "raymarch_" in k}
+        total = sum(len(v) for v in march.values())
+        mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
+        if not mine:
+            sys.exit(f"{key}: no launches of {symbol} in the {counter} pass")
+        name = max(mine, key=lambda k: len(mine[k]))
+        if 2 * len(mine[name]) < total:
+            sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass")
+        if picked is not None and name != picked:
+            sys.exit(f"{key}: the passes settled on different instances:\n {picked}\n {name}")
+        picked = name
+        vals[counter] = (sum(mine[name]) / len(mine[name]), len(mine[name]))
+    root = Path(__file__).resolve().parent.parent
+    dst = root / "profiles" / "valu.json"
+    d = json.loads(dst.read_text()) if dst.exists() else {}
+    sys.path.insert(0, str(root))
+    from bench import kernel_source_hash
+
+    d[key] = {"kernel": family, "instance": picked, "launches": vals["SQ_INSTS_VALU"][1], "valu_wave_insts": round(vals["SQ_INSTS_VALU"][0], 1),
+              "shader_cycles": round(vals["GRBM_GUI_ACTIVE"][0] / 8.0, 1), "kernel_source_hash": kernel_source_hash()}
+    dst.write_text(json.dumps(d, indent=1) + "\n")
+    print(key, family, d[key])
+
+
+if __name__ == "__main__":
+    main()
