@@ -48,6 +48,8 @@
 // whole frames bit for bit against the oracle and the other trilinear kernels.
 //
 // No MFMA: eight taps, seven lerps and a 5-flop recurrence per sample.
+#include <cstdlib>
+
 #include "vr_device.h"
 #include "vr_lds_dma.h"
 
@@ -95,6 +97,16 @@ struct TslabCfg {
 #define VR_TSLAB_STAT(...) __VA_ARGS__
 #else
 #define VR_TSLAB_STAT(...)
+#endif
+// Checked build (make TSLAB_TAG=_chk TSLAB_DEFS=-DVR_TSLAB_CHECK -> lib/libvr_core_chk.so, tests/test_tslab_plan_guard.py): the
+// staged path's correctness rests on every tap's brick lying inside the rectangle its layer was planned and loaded with -- a
+// brick outside it would alias another slot of the torus silently.  This build tests that for every staged sample (the four
+// corner pairs: brick inside the planned rectangle of a layer that is resident in this phase) and reports the number of
+// violations per pixel in place of the fetch count: 0x40000000 | staged << 29 | min(violations, 0xffff).
+#if defined(VR_TSLAB_CHECK)
+#define VR_TSLAB_CHK(...) __VA_ARGS__
+#else
+#define VR_TSLAB_CHK(...)
 #endif
 
 // PERM: per-major-axis apron copies (src = order 0, src_y = order 1, src_x = order 2), the tap pair along the first minor axis,
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
         ax_m = (g0 >= g1 && g0 >= g2) ? 0 : (g1 >= g2 ? 1 : 2);
     }
     const int ax_a = ax_m == 0 ? 1 : 0, ax_b = ax_m == 2 ? 1 : 2;
-    bool stage = no_stage == 0;                                          // (vr_set_kernel_variant 7: every tile on global taps, the cross-check of that path)
+    bool stage = no_stage != 1;                                          // (vr_set_kernel_variant 7: every tile on global taps, the cross-check of that path)
     int sgn = 1;
     {
         bool pos = true, neg = true;
@@ -422,10 +434,12 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
                 }
                 // taps: voxels floor(f - 0.5) and + 1 per axis
                 const float big = 1.0e9f;
-                const int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
-                const int hi_a = clampi((int)floorf(fmaxf(fminf(amax + 0.5f + delta, big), -big)) >> 2, 0, nbr_a - 1);
-                const int lo_b = clampi((int)floorf(fmaxf(fminf(bmin - 0.5f - delta, big), -big)) >> 2, 0, nbr_b - 1);
-                const int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
+                int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
+                int hi_a = clampi((int)floorf(fmaxf(fminf(amax + 0.5f + delta, big), -big)) >> 2, 0, nbr_a - 1);
+                int lo_b = clampi((int)floorf(fmaxf(fminf(bmin - 0.5f - delta, big), -big)) >> 2, 0, nbr_b - 1);
+                int hi_b = clampi((int)floorf(fmaxf(fminf(bmax + 0.5f + delta, big), -big)) >> 2, 0, nbr_b - 1);
+                // (the guard's negative control, checked build only: every rectangle one brick short on each side, still well-formed)
+                VR_TSLAB_CHK(if (no_stage == 3) { lo_a = min(lo_a + 1, hi_a); hi_a = max(hi_a - 1, lo_a); lo_b = min(lo_b + 1, hi_b); hi_b = max(hi_b - 1, lo_b); })
                 const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
                 plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
                 m_dda = max(m_dda, dda); m_ddb = max(m_ddb, ddb);        // every planned layer is one some phase reads or prefetches
@@ -554,6 +568,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
     };
 
     VR_TSLAB_STAT(unsigned st_samples = 0, st_iters = 0; const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();)
+    VR_TSLAB_CHK(unsigned chk_violations = 0;)
     // The staged march, compiled once per major axis M (the tables of the minor axes are 16-bit, M's 32-bit; the layer of
     // a sample is its M index >> LSH).  PA = the voxel axis along which one LDS address yields a pair of taps (the apron
     // axis of the copy the bricks came from): x, or the first minor axis in the per-axis copies (y when M is x).
@@ -587,6 +602,26 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
         };
         // (the weights are derived from ux, uy, uz by the caller AFTER the previous sample has used its own: no copies)
         float ux = 0.0f, uy = 0.0f, uz = 0.0f;
+        VR_TSLAB_CHK(int chk_idx[3] = {0, 0, 0};
+        // violations of the prepared sample's taps in phase L: voxel indices (idx_a | idx_a + 1 inside one apron slot), (idx_b, idx_b + 1), (idx_m, idx_m + 1)
+        auto check_taps = [&](int L) -> unsigned {
+            unsigned bad = 0;
+            const int ia = chk_idx[ax_a], ib = chk_idx[ax_b], im = chk_idx[ax_m];
+            for (int db = 0; db < 2; db++)
+                for (int dm = 0; dm < 2; dm++) {
+                    const int jb = min(ib + db, ndim_b - 1), jm = min(im + dm, ndim_m - 1);
+                    const int lyr = jm >> LSH;
+                    // resident in phase L: L and the layer above it (the + 1 taps), one more in the marching direction when the ring is four deep
+                    const int lo_res = sgn > 0 ? L : L - (LA >= 2 ? 1 : 0), hi_res = sgn > 0 ? L + 1 + (LA >= 2 ? 1 : 0) : L + 1;
+                    if (lyr < lo_res || lyr > hi_res || lyr < Llo || lyr > Lhi) { bad++; continue; }
+                    const uint2 e = plan[lyr];
+                    const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)(e.x >> 16), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u);
+                    const int ba = ia >> 2, bb = jb >> 2;
+                    if (ba < lo_a || ba > lo_a + dda || bb < lo_b || bb > lo_b + ddb) bad++;
+                    if (ia < 0 || ia > ndim_a - 1 || ib < 0 || im < 0) bad++;
+                }
+            return bad;
+        };)
         // CLAMP = false: the phase's samples are at least half a voxel away from the volume's low faces on every axis (the
         // tile's corner rays say so for the minor axes, the layer index for the major one), so u = f - 0.5 >= 0 without
         // the max (v_max_f32 issues at the slow rate: 3 x 4.4 of the loop's ~245 cycles)
@@ -597,6 +632,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
             if (CLAMP) { ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f); }
             else { ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f; }
             const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor: u >= 0
+            VR_TSLAB_CHK(chk_idx[0] = i0; chk_idx[1] = j0; chk_idx[2] = k0;)
             lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> LSH;
             uint32_t p0, punused = 0, q0, q1, z0, z1;
             look(std::integral_constant<int, PA>{}, PA == 0 ? i0 : j0, p0, punused);   // the second taps of the pairs are the first ones' next elements (apron)
@@ -639,6 +675,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
                     if (!__any(here ? 1 : 0)) break;
                     const bool valid = here || (alive && lay == Lnext && ahead_ok);
                     VR_TSLAB_STAT(st_iters++; st_samples += valid ? 1 : 0;)
+                    VR_TSLAB_CHK(if (valid) chk_violations += check_taps(L);)
                     const float vf = valid ? 1.0f : 0.0f;
                     VR_LDS_AS const VoxelT *p00 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a00), *p10 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a10);
                     VR_LDS_AS const VoxelT *p01 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a01), *p11 = reinterpret_cast<VR_LDS_AS const VoxelT *>((size_t)a11);
@@ -818,6 +855,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
     if (spp && threadIdx.x == 3) { spp[pix] = st_iters; return; }
     if (spp && threadIdx.x == 4) { spp[pix] = st_samples; return; }
     if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; })   // set-up: ray, head, plan, tables
+    VR_TSLAB_CHK(if (spp) { spp[pix] = 0x40000000u | ((stage && any_prefix) ? 0x20000000u : 0u) | min(chk_violations, 0xffffu); return; })
     if (spp) spp[pix] = (uint32_t)i;
 }
 
@@ -829,9 +867,11 @@ static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, cons
 {
     const uint32_t *table = NW == 16 ? L.tile_table32 : L.tile_table;
     const uint32_t blocks = NW == 16 ? L.tile_table32_blocks : L.tile_table_blocks;
+    int no_stage = L.tri_slab == 2 ? 1 : 0;
+    VR_TSLAB_CHK(if (std::getenv("VR_TSLAB_SABOTAGE") != nullptr) no_stage = 3;)   // checked build only: the plan guard's negative control
     hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM>), dim3(blocks), dim3(64 * NW), 0, st, P,
                        (const VoxelT *)vol, (const uint8_t *)L.apron, (const uint8_t *)L.apron_y, (const uint8_t *)L.apron_x, tf, fb, spp, table,
-                       L.tri_slab == 2 ? 1 : 0);
+                       no_stage);
     return hipGetLastError();
 }
 
