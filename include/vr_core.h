@@ -236,9 +236,10 @@ int vr_read_pixels(vr_handle h, float *rgba, size_t n_floats);     /* D2H of the
 int vr_read_pixels_rgba8(vr_handle h, unsigned char *rgba8, size_t n_bytes);
 /* presentation for a display that is not this GPU (replaces the reference's on-GPU blit of the target to the back
    buffer, src/RendererCore.cpp:158-162): call once per frame after vr_render.  The frame is converted to RGBA8 on the
-   launch stream and copied into one of TWO pinned host buffers on a separate copy stream, so the copy of frame i runs
+   launch stream and copied into one of THREE pinned host buffers on a separate copy stream, so the copy of frame i runs
    under the kernel of frame i + 1; *frame receives the PREVIOUS call's frame (fb_w x fb_h RGBA8, row 0 = bottom; on the
-   first call: this frame, after a wait).  The pointer stays valid until the next-but-one call.  One frame of display
+   first call: this frame, after a wait).  The pointer stays valid until the next-but-one call (call n hands out
+   slot (n - 1) % 3, call n + 1 fills slot (n + 1) % 3, call n + 2 overwrites it).  One frame of display
    latency for an interactive loop that never waits on PCIe: 0.46 ms kernel + 8 MB copy overlapped, instead of 1.3 ms
    for kernel + blocking RGBA32F read-back. */
 int vr_present_rgba8(vr_handle h, const unsigned char **frame);
@@ -280,9 +281,11 @@ const char *vr_group_transport(vr_group_handle g);     /* what vr_group_setup ch
 int vr_group_render(vr_group_handle g);
 /* the same frame without the block (replaces the reference's blocking timer read-back,
    src/RendererCore.cpp:152, for callers that can run a frame ahead): vr_group_render_async
-   enqueues the next frame into one of TWO frame slots -- shard kernels on the members' render
+   enqueues the next frame into one of THREE frame slots -- shard kernels on the members' render
    streams, gather and assembly on separate transfer streams -- and returns; at most two frames
-   may be in flight (VR_E_INVALID otherwise).  vr_group_wait blocks until the OLDEST frame in
+   may be in flight (VR_E_INVALID otherwise), so the slot of the last completed frame is never the
+   one a frame issued next is assembled into: what vr_group_framebuffer_device returned stays
+   that frame until the next vr_group_wait.  vr_group_wait blocks until the OLDEST frame in
    flight is assembled and makes it the frame vr_group_framebuffer_device / vr_group_read_pixels
    return.  Keeping one frame in flight overlaps the gather of frame i with the kernels of
    frame i + 1. */

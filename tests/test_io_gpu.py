@@ -309,12 +309,17 @@ def test_present_rgba8_is_double_buffered_and_one_frame_late(vra):
     with vra.RendererCore(0) as r:
         r.setup(size); configure(r)
         want = []
+        held = None                                         # a zero-copy view handed out one call earlier: still that frame (valid until the next-but-one call)
         for k, (ze, az) in enumerate(poses):
             r.resetCamera(); r.cameraOrient(0, ze, az)
             r.render()
             want.append(r.readPixelsRGBA8())
-            got = r.presentRGBA8()
+            got = r.presentRGBA8(copy=False)
             assert np.array_equal(got, want[max(k - 1, 0)]), k
+            if held is not None:
+                r.synchronize()                             # this call's copy has landed: it went to another buffer
+                assert np.array_equal(held, want[max(k - 2, 0)]), ("held", k)
+            held = got
         assert not np.array_equal(want[0], want[2])
         r.setup((96, 64)); r.render()                      # a new size re-allocates the presentation buffers
         assert np.array_equal(r.presentRGBA8(), r.readPixelsRGBA8())

@@ -1178,7 +1178,7 @@ void RendererCore::readPixelsRGBA8(uint8_t *rgba8, size_t n_bytes)
 void RendererCore::releasePresent()
 {
     if (present_stream_) (void)hipStreamSynchronize(present_stream_);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < kPresentSlots; s++) {
         if (d_present_[s]) { (void)hipFree(d_present_[s]); d_present_[s] = nullptr; }
         if (h_present_[s]) { (void)hipHostFree(h_present_[s]); h_present_[s] = nullptr; }
         if (present_converted_[s]) { (void)hipEventDestroy(present_converted_[s]); present_converted_[s] = nullptr; }
@@ -1203,7 +1203,7 @@ const uint8_t *RendererCore::presentRGBA8(const void *src_frame)
     if (present_capacity_ != n * 4) {
         releasePresent();
         check(hipStreamCreateWithFlags(&present_stream_, hipStreamNonBlocking), "hipStreamCreate(present)");
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < kPresentSlots; s++) {
             check(hipMalloc(&d_present_[s], n * 4), "hipMalloc(present)");
             check(hipHostMalloc(reinterpret_cast<void **>(&h_present_[s]), n * 4, hipHostMallocDefault), "hipHostMalloc(present)");
             check(hipEventCreateWithFlags(&present_converted_[s], hipEventDisableTiming), "hipEventCreate");
@@ -1211,15 +1211,18 @@ const uint8_t *RendererCore::presentRGBA8(const void *src_frame)
         }
         present_capacity_ = n * 4;
     }
-    const int s = present_count_ & 1;
-    // the slot's previous copy (two frames ago) must have left its staging buffer before it is overwritten
-    if (present_count_ >= 2) check(hipStreamWaitEvent(stream(), present_copied_[s], 0), "hipStreamWaitEvent");
+    // three slots: call n converts and copies into slot n % 3 and hands out slot (n - 1) % 3, which call n + 1 leaves alone and
+    // call n + 2 overwrites -- the pointer stays valid until the next-but-one call, as include/vr_core.h promises (round-3
+    // advisor: with two slots it was the next call)
+    const int s = present_count_ % kPresentSlots;
+    // the slot's previous copy (three frames ago) must have left its staging buffer before it is overwritten
+    if (present_count_ >= kPresentSlots) check(hipStreamWaitEvent(stream(), present_copied_[s], 0), "hipStreamWaitEvent");
     check(launch_to_rgba8(src_frame, d_present_[s], n, stream()), "to_rgba8_kernel");
     check(hipEventRecord(present_converted_[s], stream()), "hipEventRecord");
     check(hipStreamWaitEvent(present_stream_, present_converted_[s], 0), "hipStreamWaitEvent");
     check(hipMemcpyAsync(h_present_[s], d_present_[s], n * 4, hipMemcpyDeviceToHost, present_stream_), "hipMemcpy(D2H present)");
     check(hipEventRecord(present_copied_[s], present_stream_), "hipEventRecord");
-    const int ready = present_count_ == 0 ? s : (s ^ 1);                  // the previous frame; the first call waits for its own
+    const int ready = present_count_ == 0 ? s : (s + kPresentSlots - 1) % kPresentSlots;   // the previous frame; the first call waits for its own
     present_count_++;
     check(hipEventSynchronize(present_copied_[ready]), "hipEventSynchronize");
     return h_present_[ready];

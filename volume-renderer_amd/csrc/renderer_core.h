@@ -150,9 +150,10 @@ private:
     uint16_t *d_skip_grid_ = nullptr;        // dilated cell-max grid (built lazily, dropped with the volume)
     void *d_rgba8_ = nullptr;                // RGBA8 staging of the target (readPixelsRGBA8)
     size_t rgba8_capacity_ = 0;
-    void *d_present_[2] = {nullptr, nullptr};    // presentRGBA8: device staging per slot
-    uint8_t *h_present_[2] = {nullptr, nullptr}; // ... and pinned host frames
-    hipEvent_t present_converted_[2] = {nullptr, nullptr}, present_copied_[2] = {nullptr, nullptr};
+    static constexpr int kPresentSlots = 3;  // the frame handed out by call n (slot (n - 1) % 3) is written again by call n + 2: valid until the next-but-one call
+    void *d_present_[kPresentSlots] = {};    // presentRGBA8: device staging per slot
+    uint8_t *h_present_[kPresentSlots] = {}; // ... and pinned host frames
+    hipEvent_t present_converted_[kPresentSlots] = {}, present_copied_[kPresentSlots] = {};
     hipStream_t present_stream_ = nullptr;
     size_t present_capacity_ = 0;
     int present_count_ = 0;                  // frames enqueued so far

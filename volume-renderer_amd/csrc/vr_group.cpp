@@ -84,7 +84,10 @@ struct RcclApi {
 
 RcclApi g_rccl;
 
-constexpr int kSlots = 2;
+// Three frame slots, at most two frames in flight: the slot of the last COMPLETED frame -- the one vr_group_framebuffer_device /
+// read_pixels / present hand out -- is then never the target of a frame that may be issued next (round-3 advisor: with two
+// slots the second vr_group_render_async after a vr_group_wait assembled into the frame a consumer was still reading).
+constexpr int kSlots = 3, kInFlight = 2;
 
 }  // namespace
 
@@ -98,14 +101,14 @@ struct vr_group {
     std::vector<hipStream_t> xfer;
     std::vector<hipEvent_t> rendered[kSlots], sent[kSlots], t0[kSlots], t1[kSlots];
     // root device: rank-major gathered shards and the assembled frame per slot, the gather/assembly stream
-    void *gathered[kSlots] = {nullptr, nullptr};
-    float4 *frame[kSlots] = {nullptr, nullptr};
+    void *gathered[kSlots] = {};
+    float4 *frame[kSlots] = {};
     hipStream_t gather_stream = nullptr;
-    hipEvent_t assembled[kSlots] = {nullptr, nullptr};
-    bool slot_used[kSlots] = {false, false};   // the slot's events have been recorded at least once
-    int issued = 0, completed = 0;             // frames enqueued / waited for; in flight = issued - completed <= kSlots
+    hipEvent_t assembled[kSlots] = {};
+    bool slot_used[kSlots] = {};   // the slot's events have been recorded at least once
+    int issued = 0, completed = 0;             // frames enqueued / waited for; in flight = issued - completed <= kInFlight
     int current = -1;                          // slot of the last completed frame (vr_group_framebuffer_device)
-    int channels_of[kSlots] = {4, 4};
+    int channels_of[kSlots] = {4, 4, 4};
     int fb_w = 0, fb_h = 0, local_rows = 0, stripe_rows = 16, partition = 0;
     int want_rccl = 1;                         // 0 never, 1 when the devices are distinct, 2 also for a one-member group (probe: self send/recv)
     float kerneltime_sum = 0.0f;
@@ -306,12 +309,25 @@ int vr_group_setup(vr_group_handle g, int win_w, int win_h, int fb_w, int fb_h, 
     return rc;
 }
 
+// a frame that failed half-way through its issue (some members launched, others did not): nothing of it may still be running
+// when the caller issues the next one into the same slot (round-3 advisor); the frame counts as never issued
+static void drain_members(vr_group_handle g)
+{
+    for (size_t r = 0; r < g->members.size(); r++) {
+        (void)hipSetDevice(g->devices[r]);
+        vr::RendererCore &c = g->members[r]->core;
+        if (c.hasDevice()) (void)hipStreamSynchronize(c.streamHandle());
+    }
+    if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+    (void)hipGetLastError();
+}
+
 int vr_group_render_async(vr_group_handle g)
 {
     if (!g) return VR_E_INVALID;
     const int n = (int)g->members.size();
     if (!g->frame[0]) return gfail(g, VR_E_INVALID, "vr_group_render: call vr_group_setup first");
-    if (g->issued - g->completed >= kSlots) return gfail(g, VR_E_INVALID, "vr_group_render_async: two frames in flight already (call vr_group_wait)");
+    if (g->issued - g->completed >= kInFlight) return gfail(g, VR_E_INVALID, "vr_group_render_async: two frames in flight already (call vr_group_wait)");
     const int s = g->issued % kSlots;
     // (grey, alpha) shards when every member renders a grey mode: half the bytes on the wire
     bool grey = true;
@@ -339,10 +355,13 @@ int vr_group_render_async(vr_group_handle g)
             VRG_HIP(hipEventRecord(g->rendered[s][(size_t)r], c.streamHandle()));
         }
     } catch (const vr::NoDeviceError &e) {
+        drain_members(g);
         return gfail(g, VR_E_NO_DEVICE, e.what());
     } catch (const vr::HipError &e) {
+        drain_members(g);
         return gfail(g, VR_E_HIP, e.what());
     } catch (const std::exception &e) {
+        drain_members(g);
         return gfail(g, VR_E_INVALID, e.what());
     }
     hipStream_t gs = g->gather_stream;
