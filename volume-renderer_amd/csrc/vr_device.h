@@ -170,14 +170,6 @@ __device__ __forceinline__ void build_axis_tables(const FrameParams &P, uint32_t
                             : (BRICK_LZ ? (k << (BRICK_LX + BRICK_LY)) + P.bstride_z * (k >> BRICK_LZ) : P.bstride_z * k);
         }
         if (BIG) { tab[e] = t; continue; }
-#if defined(VR_EXPERIMENTS) && defined(VR_X_COLZ)
-        if (PK12) {       // z-column copy: byte offset of the COLUMN of (i, j, k) = brick * 96 + (x + 4 y) * 6; the z term holds bricks only
-            if (e < P.nx) { const uint32_t i = (uint32_t)e; tab[e] = (i >> 2) * 96u + (i & 3u) * 6u; }
-            else if (e < P.nx + P.ny) { const uint32_t j = (uint32_t)(e - P.nx); tab[e] = (j >> 2) * (uint32_t)P.bnx * 96u + (j & 3u) * 24u; }
-            else { const uint32_t k = (uint32_t)(e - P.nx - P.ny); tab[e] = (k >> 2) * (uint32_t)P.bnx * (uint32_t)P.bny * 96u; }
-            continue;
-        }
-#endif
         tab[e] = PK12 ? (uint32_t)((3ull * (uint64_t)t) >> 1) : t * (uint32_t)sizeof(VoxelT);
     }
 }

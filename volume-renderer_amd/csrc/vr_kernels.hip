@@ -280,10 +280,6 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
     } else if (!fast_tile_of_block(blockIdx.x, tiles_x, tiles_y, chunks_per_row, tx, ty)) {
         return;                                              // padding block
     }
-#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)       // per-tile shader-clock split: set-up | prefix batches | checked tail (tools/fast_stats.py)
-    const uint64_t fs0 = clock64();
-    uint64_t fs1 = fs0, fs2 = fs0;
-#endif
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const unsigned mx = lane & 7u, my = lane >> 3;
     const int lx = (int)(tx * FAST_TILE_W + (wave & 3u) * 8u + mx);
@@ -339,9 +335,6 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         }
     }
 
-#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
-    fs1 = clock64();
-#endif
     float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f;   // MODE 0/1: r == g == b bit for bit, only drgb is carried
     uint32_t fetches = 0;
     {                                   // every thread runs the (barrier-carrying) batch loop
@@ -455,14 +448,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         // consume(), not of issue() -- as a 32-bit value it would be materialised (and the loads waited for) at
         // the end of the divergent region the gathers are issued in.
         using RawT = typename std::conditional<BIG, uint32_t, VoxelT>::type;
-#if defined(VR_EXPERIMENTS) && defined(VR_X_COLZ)
-        constexpr bool COLZ = PK12 && BATCH == 8 && !SKIPT && ATAB && !BIG;
-#else
-        constexpr bool COLZ = false;
-#endif
-        struct ColB { uint64_t w0[2], w1[2]; uint32_t meta; };    // (COLZ) two column words per group of four samples; 4 bits per sample: in a column | second column | z & 3
-        uint32_t colz_fallbacks = 0;
-        auto issue = [&](RawT (&v)[BATCH], uint32_t &nib, bool commit, ColB &cb) -> bool {   // nib (PK12): bit offset (0 / 4) of sample u in nibble u
+        auto issue = [&](RawT (&v)[BATCH], uint32_t &nib, bool commit) -> bool {   // nib (PK12): bit offset (0 / 4) of sample u in nibble u
             const float Qx0 = Qx, Qy0 = Qy, Qz0 = Qz, qx0 = qx, qy0 = qy, qz0 = qz;
             bool skip = false;
             if (skip_on) {
@@ -479,7 +465,6 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 return true;
             }
             typename VoxelAddr<LAYOUT, BIG>::type off[BATCH];
-            [[maybe_unused]] uint32_t cxy[BATCH], ctz[BATCH], cfz[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 int vi, vj, vk;
@@ -496,44 +481,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     qx += dsx; qy += dsy; qz += dsz;
                 }
                 if (ATAB && BIG) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)((uint64_t)(tab_x[vi] + tab_y[vj]) + ((uint64_t)tab_z[vk] << 4));   // elements
-                else if (ATAB && COLZ) { cxy[u] = tab_x[vi] + tab_y[vj]; ctz[u] = tab_z[vk]; cfz[u] = (uint32_t)vk & 3u; off[u] = 0; }
                 else if (ATAB) off[u] = (typename VoxelAddr<LAYOUT, BIG>::type)(tab_x[vi] + tab_y[vj] + tab_z[vk]);   // bytes
                 else off[u] = VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk);
-                if (PK12 && !COLZ) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);   // odd x: upper 12 of the 16 bits
+                if (PK12) nib = u == 0 ? ((uint32_t)vi & 1u) << 2 : ((((uint32_t)vi & 1u) << (4 * u + 2)) | nib);   // odd x: upper 12 of the 16 bits
             }
-#if defined(VR_EXPERIMENTS) && defined(VR_X_COLZ)
-            // experiment (round 4): SPECULATIVE Z-COLUMNS.  The 12-bit copy stores every brick's (x, y) columns of four z voxels
-            // contiguously (6 B).  Per group of four samples: the column of the first sample and the column the fourth sample's z
-            // falls in at the first sample's (x, y) are fetched with one 8-byte load each; a later sample of the group takes its
-            // voxel from them when it shares the first one's (x, y) (integer compares); the others are fetched one by one
-            // (masked 2-byte gathers).  Bit-identical frames; the question is the time.
-            if constexpr (COLZ) {
-                typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-                uint32_t meta = 0;
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const int b0 = 4 * g;
-                    const u2_t c0 = __builtin_amdgcn_raw_buffer_load_b64(rs12, (int)(cxy[b0] + ctz[b0]), 0, 0);
-                    const u2_t c1 = __builtin_amdgcn_raw_buffer_load_b64(rs12, (int)(cxy[b0] + ctz[b0 + 3]), 0, 0);
-                    cb.w0[g] = (uint64_t)c0.x | ((uint64_t)c0.y << 32);
-                    cb.w1[g] = (uint64_t)c1.x | ((uint64_t)c1.y << 32);
-#pragma unroll
-                    for (int u = b0; u < b0 + 4; u++) {
-                        const bool ok = cxy[u] == cxy[b0] && (ctz[u] == ctz[b0] || ctz[u] == ctz[b0 + 3]);
-                        const uint32_t m = (ok ? 1u : 0u) | (ctz[u] != ctz[b0] ? 2u : 0u) | (cfz[u] << 2);
-                        meta |= m << (4 * u);
-                        v[u] = 0;
-                        if (!ok) v[u] = (RawT)__builtin_amdgcn_raw_buffer_load_b16(rs12, (int)(cxy[u] + ctz[u] + ((cfz[u] * 3u) >> 1)), 0, 0);
-                    }
-                }
-                cb.meta = meta;
-                if (SPEC && !commit) {
-                    if (POW2) { Qx = Qx0; Qy = Qy0; Qz = Qz0; }
-                    else { qx = qx0; qy = qy0; qz = qz0; }
-                }
-                return false;
-            }
-#endif
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (ATAB && !BIG) {
@@ -569,21 +520,14 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             }
         };
         // PK12: the 12 bits of sample u start at bit 0 or 4 of the 16 loaded (nibble u of nib)
-        auto texel_of = [&](RawT raw, uint32_t nib, int u, const ColB &cb) -> uint32_t {
-            if (COLZ) {
-                const uint32_t m = (cb.meta >> (4 * u)) & 15u, f = m >> 2;
-                const uint64_t w = (m & 2u) ? cb.w1[u >> 2] : cb.w0[u >> 2];
-                const uint32_t from_col = (uint32_t)(w >> (12u * f)) & 0xfffu, single = ((uint32_t)raw >> ((f & 1u) * 4u)) & 0xfffu;
-                return (m & 1u) ? from_col : single;
-            }
+        auto texel_of = [&](RawT raw, uint32_t nib, int u) -> uint32_t {
             if (!PK12) return (uint32_t)raw;
             const uint32_t sh = __builtin_amdgcn_ubfe(nib, 4 * u, 4);
             __builtin_assume(sh <= 4u);
             return ((uint32_t)raw >> sh) & 0xfffu;
         };
-        auto consume_live = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib, const ColB &cb) -> bool {
+        auto consume_live = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib) -> bool {
             if (skipped) { i += BATCH; return false; }   // every sample of the batch adds exactly zero
-            if (COLZ) colz_fallbacks += 8u - (uint32_t)__builtin_popcount(cb.meta & 0x11111111u);
             float c[BATCH], cg[BATCH], cbl[BATCH], a[BATCH];
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             float da_last = 0.0f;
@@ -591,9 +535,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             // latency hides behind the first half's dependent compositing chain
             constexpr int HALF = BATCH / 2;
 #pragma unroll
-            for (int u = 0; u < HALF; u++) classify(texel_of(v[u], nib, u, cb), c[u], cg[u], cbl[u], a[u]);
+            for (int u = 0; u < HALF; u++) classify(texel_of(v[u], nib, u), c[u], cg[u], cbl[u], a[u]);
 #pragma unroll
-            for (int u = HALF; u < BATCH; u++) classify(texel_of(v[u], nib, u, cb), c[u], cg[u], cbl[u], a[u]);
+            for (int u = HALF; u < BATCH; u++) classify(texel_of(v[u], nib, u), c[u], cg[u], cbl[u], a[u]);
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
                 if (u == BATCH - 1) da_last = da;
@@ -611,10 +555,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         };
         // PIPE: every lane of the wavefront runs the batch (no branch between the gathers and their use, see
         // issue()); the lanes that are not `live` get their state back.
-        auto consume = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib, bool live, const ColB &cb) -> bool {
+        auto consume = [&](const RawT (&v)[BATCH], bool skipped, uint32_t nib, bool live) -> bool {
             const float drgb0 = drgb, dg0 = dg, db0 = db, da0 = da;
             const int i0 = i;
-            bool term = consume_live(v, skipped, nib, cb);
+            bool term = consume_live(v, skipped, nib);
             if (SPEC && !live) { drgb = drgb0; dg = dg0; db = db0; da = da0; i = i0; term = false; }
             return term;
         };
@@ -656,14 +600,13 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         // fetched for one wavefront is still in the CU's L1 when its neighbours need it.
         {
             RawT va[BATCH], vb[BATCH];
-            ColB ca = {}, cbb = {};
             uint32_t nib_a = 0, nib_b = 0;
             bool skip_a = false, skip_b = false;
             int b = 0;
             bool fin = nb == 0;
             if (!fin) {
                 if (skip_on) cell_next = probe(0);
-                skip_a = issue(va, nib_a, true, ca);
+                skip_a = issue(va, nib_a, true);
             }
             // lockstep: one plain barrier per 16 samples; every 4th doubles as the vote "all rays finished"
             // (__syncthreads_and is three barriers and a cross-lane reduction: 0.464 -> 0.458 ms on cfg3)
@@ -675,30 +618,27 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     // eight it is about to use, on every path (ISA: vmcnt(15) ... vmcnt(8))
                     if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) continue;      // nothing left in this wavefront
                     bool live = !fin;
-                    skip_b = issue(vb, nib_b, live && b + 1 < nb, cbb);
-                    if (consume(va, skip_a, nib_a, live, ca)) { done = true; fin = true; }
+                    skip_b = issue(vb, nib_b, live && b + 1 < nb);
+                    if (consume(va, skip_a, nib_a, live)) { done = true; fin = true; }
                     else if (live && ++b >= nb) fin = true;
                     live = !fin;
-                    skip_a = issue(va, nib_a, live && b + 1 < nb, ca);
-                    if (consume(vb, skip_b, nib_b, live, cbb)) { done = true; fin = true; }
+                    skip_a = issue(va, nib_a, live && b + 1 < nb);
+                    if (consume(vb, skip_b, nib_b, live)) { done = true; fin = true; }
                     else if (live && ++b >= nb) fin = true;
                     continue;
                 }
                 if (!fin) {
-                    if (b + 1 < nb) skip_b = issue(vb, nib_b, true, cbb);
-                    if (consume(va, skip_a, nib_a, true, ca)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_b = issue(vb, nib_b, true);
+                    if (consume(va, skip_a, nib_a, true)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
                 if (!fin) {
-                    if (b + 1 < nb) skip_a = issue(va, nib_a, true, ca);
-                    if (consume(vb, skip_b, nib_b, true, cbb)) { done = true; fin = true; }
+                    if (b + 1 < nb) skip_a = issue(va, nib_a, true);
+                    if (consume(vb, skip_b, nib_b, true)) { done = true; fin = true; }
                     else if (++b >= nb) fin = true;
                 }
             }
         }
-#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
-        fs2 = clock64();
-#endif
         // back to box units for the tail (exact: S is a power of two); the step is re-derived
         // from its scaled copy so that only one of the two is live across the batch loop
         float tsx = dsx, tsy = dsy, tsz = dsz;
@@ -712,20 +652,12 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
         }
         fetches = (uint32_t)i;
-        if (COLZ) fetches = colz_fallbacks;      // experiment: the per-pixel "fetch count" reports the samples that were NOT served by a column
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;
     if (MODE >= 2) store_pixel(P, fb, pix, drgb, dg, db, da);
     else if (MODE == 1) store_pixel(P, fb, pix, da, da, da, da);
     else store_pixel(P, fb, pix, drgb, drgb, drgb, da);
-#if defined(VR_EXPERIMENTS) && defined(VR_X_FSTATS)
-    if (spp && threadIdx.x < 4) {
-        const uint64_t fs3 = clock64();
-        spp[pix] = threadIdx.x == 0 ? 0x80000000u | (uint32_t)(fs1 - fs0) : (threadIdx.x == 1 ? (uint32_t)(fs2 - fs1) : (threadIdx.x == 2 ? (uint32_t)(fs3 - fs2) : fetches));
-        return;
-    }
-#endif
     if (spp) spp[pix] = fetches;
 }
 
@@ -1974,30 +1906,9 @@ __global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ s
     }
 }
 
-#if defined(VR_EXPERIMENTS) && defined(VR_X_COLZ)
-// experiment (round 4, "speculative z-columns"): the 12-bit copy with every brick's 16 (x, y) columns of four z voxels stored
-// contiguously -- column c = x + 4 y of a brick at byte 6 c, voxel z in bits [12 z, 12 z + 12) of the column's 48
-__global__ __launch_bounds__(256) void pack12z_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, uint64_t ncols)
-{
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += stride) {
-        const uint64_t brick = c >> 4;
-        const uint32_t xy = (uint32_t)(c & 15u);
-        const uint16_t *b = src + brick * 64u + xy;
-        const uint32_t v0 = b[0] & 0xfffu, v1 = b[16] & 0xfffu, v2 = b[32] & 0xfffu, v3 = b[48] & 0xfffu;
-        dst[3 * c + 0] = (uint16_t)(v0 | (v1 << 12));
-        dst[3 * c + 1] = (uint16_t)((v1 >> 4) | (v2 << 8));
-        dst[3 * c + 2] = (uint16_t)((v2 >> 8) | (v3 << 4));
-    }
-}
-#endif
 
 hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStream_t st)
 {
-#if defined(VR_EXPERIMENTS) && defined(VR_X_COLZ)
-    hipLaunchKernelGGL(pack12z_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint16_t *)src_u16, (uint16_t *)dst, voxels / 4u);
-    return hipGetLastError();
-#endif
     hipLaunchKernelGGL(pack12_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src_u16, (uint32_t *)dst, voxels / 8u);
     return hipGetLastError();
 }

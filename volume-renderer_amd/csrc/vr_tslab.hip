@@ -69,10 +69,7 @@ namespace vr {
 //   NW = 8,  LDSKB = 160: the 32x16 tile with the whole LDS: everything fits, at 8 wavefronts per CU (views along a body
 //                         diagonal of the volume: 2.47 ms against 2.7-2.9 for the other two).
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
-#ifndef VR_X_FB_BATCH
-#define VR_X_FB_BATCH 4
-#endif
-constexpr int TS_FB_BATCH = VR_X_FB_BATCH;                            // samples whose taps a tile that is not staged requests together
+constexpr int TS_FB_BATCH = 4;                            // samples whose taps a tile that is not staged requests together (six or eight: no faster)
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
 template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM>
