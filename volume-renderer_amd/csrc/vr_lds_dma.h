@@ -21,6 +21,16 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// the same with the source as a wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit byte offset: the address
+// arithmetic of a piece is then 32-bit per lane, the 64-bit part is scalar
+__device__ __forceinline__ void glds16_rel(const void *gbase, uint32_t rel, uint32_t lds_dst)
+{
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(rel), "s"(gbase), "s"(lds_dst) : "memory");
+}
+
 // wait until at most n of this wavefront's vector-memory operations are outstanding (they
 // complete in order, so everything issued before the last n has landed)
 __device__ __forceinline__ void slab_wait_pieces(int n)

@@ -488,10 +488,16 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
     const uint32_t sA = sel3(ax_a, str0, str1, str2), sB = sel3(ax_b, str0, str1, str2), sM = sel3(ax_m, str0, str1, str2);
     // per-lane loader constants of piece q: torus coordinates (ta, tb) of the slot this lane's 16-byte chunk belongs to,
     // the chunk's index inside the slot, and whether the slot exists
-    int ld_ta[C::MAX_PIECES], ld_tb[C::MAX_PIECES], ld_part[C::MAX_PIECES];
-    bool ld_ok[C::MAX_PIECES];
+    // ... and ld_rel: the byte offset of that chunk's source relative to the layer's torus origin, (ta * sA + tb * sB) * brick bytes
+    // + 16 * chunk: per layer only the wrap-around terms are added (32-bit per lane; the 64-bit part of the address is scalar)
+    int ld_ta[C::MAX_PIECES], ld_tb[C::MAX_PIECES];
+    uint32_t ld_rel[C::MAX_PIECES];
 #pragma unroll
-    for (int q = 0; q < C::MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = ld_part[q] = 0; ld_ok[q] = false; }
+    for (int q = 0; q < C::MAX_PIECES; q++) { ld_ta[q] = ld_tb[q] = 0x3fffffff; ld_rel[q] = 0; }      // (a slot that does not exist: beyond every rectangle)
+    // the wrap-around terms: a torus column / row below the rectangle's origin holds the brick one ring further
+    const uint32_t wrap_a = (uint32_t)RA * sA * (uint32_t)C::BRICK_BYTES, wrap_b = (uint32_t)RB * sB * (uint32_t)C::BRICK_BYTES;
+    // (relative offsets are 32-bit: (RA + 1) * sA + (RB + 1) * sB bricks must stay below 2^31 bytes -- any volume a GPU holds)
+    if ((uint64_t)(RA + 1) * (uint64_t)sA * (uint64_t)C::BRICK_BYTES + (uint64_t)(RB + 1) * (uint64_t)sB * (uint64_t)C::BRICK_BYTES >= (1ull << 31)) stage = false;
     if (stage && any_prefix) {
         // torus position of every layer's rectangle origin (second word of the plan entries)
         for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
@@ -523,45 +529,39 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
         for (int q = 0; q < C::MAX_PIECES; q++) {
             const int c = (q * TS_NW + (int)wave) * 64 + (int)lane;
             const int slot = CHR == 5 ? c / 5 : (CHR == 10 ? c / 10 : c / CHR);
-            ld_part[q] = c - slot * CHR;
-            ld_tb[q] = slot / RA;
-            ld_ta[q] = slot - ld_tb[q] * RA;
-            ld_ok[q] = slot < RA * RB && q < pieces;
+            const int part = c - slot * CHR, tb = slot / RA, ta = slot - tb * RA;
+            if (slot < RA * RB && q < pieces) {
+                ld_ta[q] = ta; ld_tb[q] = tb;
+                ld_rel[q] = ((uint32_t)ta * sA + (uint32_t)tb * sB) * (uint32_t)C::BRICK_BYTES + (uint32_t)part * 16u;
+            }
         }
     }
     __syncthreads();
     const uint32_t ring_base = lds_offset_of(slots);
 
-    // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ; returns the number of DMA
-    // instructions this wavefront issued
-    auto issue_layer = [&](int L) -> int {
-        if (L < Llo || L > Lhi) return 0;
+    // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ.  Per lane and piece: two wrap-around tests
+    // (is this lane's torus column / row below the rectangle's torus origin?), two extent tests, two masked adds -- the layer's
+    // base address (source copy + the brick of torus origin (0, 0) + the half of the brick) is scalar arithmetic
+    auto issue_layer = [&](int L) {
+        if (L < Llo || L > Lhi) return;
         const uint2 e = plan[L];
         const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
         const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
         const int dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u), la = (int)((ey >> 16) & 255u), lb = (int)(ey >> 24);
         const int lz = L % RZ;
         // brick layer and, for half layers, which half of the brick (its first or last two planes along m: 40 contiguous voxels)
-        const uint32_t layer_idx = (uint32_t)(L >> (2 - LSH)) * sM;
-        const uint32_t half_off = LSH == 1 ? (uint32_t)(L & 1) * (uint32_t)(C::BRICK_BYTES / 2) : 0u;
-        int n = 0;
+        const uint64_t origin = (uint64_t)(uint32_t)(lo_a - la) * sA + (uint64_t)(uint32_t)(lo_b - lb) * sB + (uint64_t)(uint32_t)(L >> (2 - LSH)) * sM;
+        const uint8_t *const base = src_m + origin * (uint64_t)C::BRICK_BYTES + (LSH == 1 ? (uint64_t)(L & 1) * (uint64_t)(C::BRICK_BYTES / 2) : 0ull);
+        const uint32_t dst = ring_base + (uint32_t)lz * layer_bytes + (uint32_t)wave * 1024u;
 #pragma unroll
         for (int q = 0; q < C::MAX_PIECES; q++) {
             if (q >= pieces) break;
-            int oa = ld_ta[q] - la, ob = ld_tb[q] - lb;
-            if (oa < 0) oa += RA;
-            if (ob < 0) ob += RB;
-            const bool ok = ld_ok[q] && oa <= dda && ob <= ddb;
-            if (__any(ok ? 1 : 0)) {
-                if (ok) {
-                    const uint32_t brick = __umul24((uint32_t)(lo_a + oa), sA) + __umul24((uint32_t)(lo_b + ob), sB) + layer_idx;
-                    const uint8_t *g = src_m + (uint64_t)brick * (uint64_t)C::BRICK_BYTES + (uint64_t)(half_off + (uint32_t)(ld_part[q] * 16));
-                    glds16(g, ring_base + (uint32_t)lz * layer_bytes + (uint32_t)(q * TS_NW + (int)wave) * 1024u);
-                }
-                n++;
-            }
+            const int da_ = ld_ta[q] - la, db_ = ld_tb[q] - lb;
+            const int ma = da_ >> 31, mb = db_ >> 31;                   // all ones: wraps around
+            const int oa = da_ + (ma & RA), ob = db_ + (mb & RB);
+            if (oa <= dda && ob <= ddb)
+                glds16_rel(base, ld_rel[q] + ((uint32_t)ma & wrap_a) + ((uint32_t)mb & wrap_b), dst + (uint32_t)(q * TS_NW) * 1024u);
         }
-        return n;
     };
 
     VR_TSLAB_STAT(unsigned st_samples = 0, st_iters = 0; const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();)
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
         constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0;          // minor axes: A and the other one
         constexpr int PA = PERM ? A : 0, O1 = PA == 0 ? 1 : 0, O2 = 2;         // the other two voxel axes, in x-y-z order
         // ---- prologue: the layers phases 0 .. LA-1 read
-        if (sgn > 0) { for (int l = 0; l <= LA; l++) (void)issue_layer(L0 + l); }
-        else { for (int l = 1; l >= 1 - LA; l--) (void)issue_layer(L0 + l); }
+        if (sgn > 0) { for (int l = 0; l <= LA; l++) issue_layer(L0 + l); }
+        else { for (int l = 1; l >= 1 - LA; l--) issue_layer(L0 + l); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // prepared sample (the one at the current position): tap BYTE addresses of the four corner pairs -- (O1, O2) = (0,0),
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
         for (int p = 0; p < n_phases; p++) {
             const int L = L0 + sgn * p, Lnext = L + sgn;
             // the layer that phase p + LA reads first
-            const int n_new = issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
+            issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
             // ---- this phase's samples: the ones whose cell lies in layer L.  The body is straight-line code for the whole
             // wavefront: a lane without a sample in this layer reads taps at its (valid, unchanged) prepared addresses and
             // drops the result -- exec-mask branches around the body cost more scalar instructions than the arithmetic
@@ -660,6 +660,11 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
             // shader's test before every sample, VolumeRenderer.cs:118; dest.a never decreases).
             // (a second, select-free copy of the body for the iterations in which every lane has a sample -- four out of five --
             // measured SLOWER: 1.65 vs 1.51 ms; the look-ups issued at the end of one copy are consumed by either)
+            // (round 4, ISA inspection: entering and leaving the sample loop costs 29 v_mov per phase -- the register allocator
+            // keeps the 14 loop-carried values in other registers outside it.  Two restructurings that avoid those were built
+            // and measured SLOWER, because the copies then moved INTO the sample loop: one loop per clamped / unclamped stretch
+            // of phases with a single copy of the body (1.25 -> 1.30 ms), and phases + samples as one flat loop with the end of
+            // a phase as a wave-uniform branch (1.34 ms; there the compiler also waits for taps and look-ups together))
             auto phase_samples = [&](auto clamp_tag) {
                 for (;;) {
                     // RZ = 4: the layer BEHIND the two this phase reads is resident as well (requested two phases ago, landed before
@@ -727,7 +732,6 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
             else phase_samples(std::false_type{});
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
-            (void)n_new;
             slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
             // every 8th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
             if ((p & 7) == 7) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
