@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."; REPO=$PWD; export TMPDIR=/tmp
 run() {   # key, bench args...
   KEY=$1; shift
   OUT=$REPO/gpurun_out/traffic_$KEY; mkdir -p "$OUT"
-  CMD="python $REPO/bench.py --steps 6 --warmup 2 --clock-ramp-frames 40 --no-cpu-baseline --no-extras $*"
+  CMD="python $REPO/bench.py --steps 6 --warmup 2 --clock-ramp-frames 120 --no-cpu-baseline --no-extras $*"
   (cd /tmp; for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU GRBM_GUI_ACTIVE; do
      timeout -k 5 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o run -- $CMD > "$OUT/$C.log" 2>&1
    done)

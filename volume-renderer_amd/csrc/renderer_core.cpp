@@ -832,18 +832,36 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         // one re-measurement at sustained clocks: whatever settled during the clock ramp is checked again, once
         if (!e.revalidated && ++e.frames_settled >= kTuneRevalidateFrames) {
             e.revalidated = true;
-            for (int c = 0; c < e.ncand; c++) { e.tries[c] = 0; e.best_ms[c] = 0.0f; }
+            for (int c = 0; c < e.ncand; c++) { e.tries[c] = 0; e.issued[c] = 0; e.best_ms[c] = 0.0f; }
             e.settled = -1;
             e.next = 0;
         }
-    } else if (tune_count_ >= kTuneSlots) {                              // every event pair is in flight: best so far
-        use = 0;
-        for (int c = 1; c < e.ncand; c++)
-            if (e.tries[c] > 0 && (e.tries[use] == 0 || e.best_ms[c] < e.best_ms[use])) use = c;
     } else {
-        use = e.next;
-        e.next = (e.next + 1) % e.ncand;
-        tune_measure_ = true; tune_key_ = key; tune_cand_ = use;
+        // the next candidate that still needs a measurement launched; when every measurement is in flight (a burst of
+        // asynchronous frames) or every event pair is taken: the best so far, the heuristic's choice before any result
+        int pick = -1;
+        if (tune_count_ < kTuneSlots)
+            for (int k = 0; k < e.ncand && pick < 0; k++) {
+                const int c = (e.next + k) % e.ncand;
+                if (e.issued[c] < kTuneTries) pick = c;
+            }
+        if (pick >= 0) {
+            use = pick;
+            e.issued[pick]++;
+            e.next = (pick + 1) % e.ncand;
+            tune_measure_ = true; tune_key_ = key; tune_cand_ = use;
+        } else {
+            int best = -1;
+            for (int c = 0; c < e.ncand; c++)
+                if (e.tries[c] > 0 && (best < 0 || e.best_ms[c] < e.best_ms[best])) best = c;
+            if (best < 0)
+                for (int c = 0; c < e.ncand; c++) if (e.cand[c] == e.heur) best = c;
+            use = best < 0 ? 0 : best;
+            // a measurement whose events were lost (a failed launch) would leave the entry waiting for ever: with nothing in
+            // flight, whatever has not reported is launched again
+            if (tune_count_ == 0)
+                for (int c = 0; c < e.ncand; c++) if (e.tries[c] < kTuneTries) e.issued[c] = e.tries[c];
+        }
     }
     const int c = e.cand[use];
     L.sparse_shard = (c & 1) ? 1 : 0; L.pipelined = (c & 2) ? 1 : 0; L.short_batches = (c & 4) ? 1 : 0; L.tri_slab = (c >> 3) & 15;

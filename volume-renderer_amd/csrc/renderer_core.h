@@ -191,7 +191,7 @@ private:
     // ~25 frames after idle run ~15 % slow while the clocks ramp) and is evicted least-recently-used first.
     static constexpr int kTuneCand = 6, kTuneTries = 2, kTuneRevalidateFrames = 96, kTuneEntries = 512;
     struct TuneEntry {
-        int ncand = 0, cand[kTuneCand] = {}, tries[kTuneCand] = {}, settled = -1, next = 0;
+        int ncand = 0, cand[kTuneCand] = {}, tries[kTuneCand] = {}, issued[kTuneCand] = {}, settled = -1, next = 0;   // issued: measurements launched (a burst of asynchronous frames launches kTuneTries per candidate, not one per frame until the results arrive)
         int heur = 0;                        // the heuristic's choice (a candidate value): it wins ties
         float best_ms[kTuneCand] = {};
         int frames_settled = 0;              // launches since it settled
