@@ -118,6 +118,8 @@ def model(c, tile_w, tile_h, T):
     return np.array(out)
 
 
+if __name__ != "__main__":
+    raise SystemExit      # (imported for model() / poses(): tools/model/tslab_tileshape.py)
 configs = [  # name, tile_w, tile_h, T, slot bytes, LDS bytes per workgroup
     ("32x16 T4 160B  80K (r3)", 32, 16, 4, 160, 80),
     ("32x16 T4 160B 160K (v8)", 32, 16, 4, 160, 160),

@@ -21,12 +21,12 @@ if pose == "offaxis":
 elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
     r.cameraOrient(0.0, *[float(v) for v in pose.split(",")])
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 6
-TH = 32 if variant == 9 else 16              # rows per tile
+TH, TWP = (32, 32) if variant == 9 else ((32, 16) if variant == 11 else (16, 32))              # rows per tile
 r.setKernelVariant(variant)
 r.render()
 print("kernel", r.last_kernel_name)
 _, spp = r.countSamples(per_pixel=True)
-st = spp[::TH, ::32]
+st = spp[::TH, ::TWP]
 m = (st & 0x80000000) != 0
 v = st[m]
 staged, rz, half, slots, phases = v & 1, (v >> 4) & 7, (v >> 7) & 1, (v >> 8) & 255, (v >> 16) & 4095
@@ -34,8 +34,8 @@ print("why not staged (1 corner rays disagree on / graze the major axis, 2 layer
 print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} ({staged.mean():.3f}), of them in half layers {int((staged & half).sum())}; RZ histogram {np.bincount(rz)[:6]}; "
       f"RA*RB of staged tiles min/mean/max {slots[staged == 1].min() if staged.any() else 0}/{slots[staged == 1].mean() if staged.any() else 0:.1f}/{slots[staged == 1].max() if staged.any() else 0}; "
       f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
-clk, wall, iters, samp = spp[::TH, 1::32][m].astype(np.float64), spp[::TH, 2::32][m].astype(np.float64), spp[::TH, 3::32][m].astype(np.float64), spp[::TH, 4::32][m].astype(np.float64)
-setup = spp[::TH, 5::32][m].astype(np.float64)
+clk, wall, iters, samp = spp[::TH, 1::TWP][m].astype(np.float64), spp[::TH, 2::TWP][m].astype(np.float64), spp[::TH, 3::TWP][m].astype(np.float64), spp[::TH, 4::TWP][m].astype(np.float64)
+setup = spp[::TH, 5::TWP][m].astype(np.float64)
 ok = wall > 0
 print(f"set-up before the march (ray, checked head, load plan, tables): mean {setup[ok].mean():.0f} ticks = {100 * setup[ok].sum() / (setup[ok].sum() + clk[ok].sum()):.1f} % of the tiles' time")
 for flag, name in ((1, "staged"), (0, "not staged")):

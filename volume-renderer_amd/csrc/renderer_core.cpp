@@ -49,6 +49,7 @@ RendererCore::~RendererCore()
         if (d_tf_) (void)hipFree(d_tf_);
         if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_tile_table32_) (void)hipFree(d_tile_table32_);
+        if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
@@ -622,8 +623,8 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    // kernel variants 6 .. 10: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
-    L.tri_slab = (force_generic >= 6 && force_generic <= 10) ? force_generic - 5 : 0;
+    // kernel variants 6 .. 11: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
+    L.tri_slab = (force_generic >= 6 && force_generic <= 11) ? force_generic - 5 : 0;
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -774,6 +775,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
             add(3 << 3);
             if (L.tile_table32 != nullptr) add(4 << 3);
             add(5 << 3);
+            if (L.tile_table_tall != nullptr) add(6 << 3);
         }
     }
     if (n < 2) return;
@@ -934,9 +936,9 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     last_apron_bytes_ = apron_bytes_;
     // Half layers of the staged kernel (vr_tslab.hip, 16-bit volumes): two more copies with the bricks' planes along y / x
     // slowest, so that half a brick along any major axis is 80 contiguous bytes.  Built the first time a view is oblique
-    // to the volume axes (or kernel variants 8 .. 10 ask for them); +2 x 1.25 volumes of HBM.
+    // to the volume axes (or kernel variants 8 .. 11 ask for them); +2 x 1.25 volumes of HBM.
     const bool oblique = viewAxisAlignment(P) < 0.92;
-    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 10) || (force_generic == 0 && oblique));
+    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 11) || (force_generic == 0 && oblique));
     if (want_perm && !apron_perm_failed_) {
         for (int o = 0; o < 2 && !apron_perm_failed_; o++) {
             if (d_apron_perm_[o]) continue;
@@ -1030,8 +1032,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
 {
     L.tile_table = nullptr;
     L.tile_table_blocks = 0;
-    L.tile_table32 = nullptr;
-    L.tile_table32_blocks = 0;
+    L.tile_table32 = L.tile_table_tall = nullptr;
+    L.tile_table32_blocks = L.tile_table_tall_blocks = 0;
     if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
@@ -1058,11 +1060,14 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
             blocks = t.size();
         };
         upload(d_tile_table_, tile_table_capacity_, tile_table_blocks_, table);
-        tile_table32_blocks_ = 0;
+        tile_table32_blocks_ = tile_table_tall_blocks_ = 0;
         if (need32) {
             std::vector<uint32_t> t32;
             (void)buildTileSchedule(P, rows, t32, nullptr, 32u);
             upload(d_tile_table32_, tile_table32_capacity_, tile_table32_blocks_, t32);
+            std::vector<uint32_t> tall;
+            (void)buildTileSchedule(P, rows, tall, nullptr, 32u, 16u);
+            upload(d_tile_table_tall_, tile_table_tall_capacity_, tile_table_tall_blocks_, tall);
         }
         tile_table_key_ = shape_key;
         std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
@@ -1070,6 +1075,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
     if (need32 && tile_table32_blocks_ > 0) { L.tile_table32 = d_tile_table32_; L.tile_table32_blocks = (uint32_t)tile_table32_blocks_; }
+    if (need32 && tile_table_tall_blocks_ > 0) { L.tile_table_tall = d_tile_table_tall_; L.tile_table_tall_blocks = (uint32_t)tile_table_tall_blocks_; }
     // Kernel choice per launch (all bit-identical; measured on cfg3 after the checked-head fix, tools/pose_sweep.py and
     // tools/shard_ms.py; `aligned` = central ray within ~23 degrees of a volume axis):
     //   * relay kernel (4 wavefronts per 8x8 tile) for launches far from filling the chip -- fewer than 256 active

@@ -175,6 +175,8 @@ private:
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
     uint32_t *d_tile_table32_ = nullptr;     // the same for 32x32-pixel tiles (vr_tslab.hip: 16-wavefront workgroups; 16-bit volumes); built with the table above
     size_t tile_table32_capacity_ = 0, tile_table32_blocks_ = 0;
+    uint32_t *d_tile_table_tall_ = nullptr;  // ... and for 16x32-pixel tiles (8 wavefronts, two wide)
+    size_t tile_table_tall_capacity_ = 0, tile_table_tall_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
     unsigned tile_active_ = 0;               // tiles with work in the cached schedule
@@ -189,7 +191,7 @@ private:
     // An entry settles on the fastest candidate after kTuneTries measurements of each (in an order shuffled per entry, so no
     // candidate is always the one measured on cold clocks), is measured ONCE more kTuneRevalidateFrames frames later (the first
     // ~25 frames after idle run ~15 % slow while the clocks ramp) and is evicted least-recently-used first.
-    static constexpr int kTuneCand = 6, kTuneTries = 2, kTuneRevalidateFrames = 96, kTuneEntries = 512;
+    static constexpr int kTuneCand = 8, kTuneTries = 2, kTuneRevalidateFrames = 96, kTuneEntries = 512;
     struct TuneEntry {
         int ncand = 0, cand[kTuneCand] = {}, tries[kTuneCand] = {}, issued[kTuneCand] = {}, settled = -1, next = 0;   // issued: measurements launched (a burst of asynchronous frames launches kTuneTries per candidate, not one per frame until the results arrive)
         int heur = 0;                        // the heuristic's choice (a candidate value): it wins ties

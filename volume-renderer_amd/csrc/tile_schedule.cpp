@@ -100,11 +100,11 @@ uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
     return hsh;
 }
 
-unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples, unsigned tile_h)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples, unsigned tile_h, unsigned tile_w)
 {
     unsigned active_tiles = 0;
     double longest = 0.0;
-    const unsigned tiles_x = (unsigned)((P.img_w + (int)kFastTileW - 1) / (int)kFastTileW);
+    const unsigned tiles_x = (unsigned)((P.img_w + (int)tile_w - 1) / (int)tile_w);
     const unsigned tiles_y = (unsigned)((rows + (int)tile_h - 1) / (int)tile_h);
     // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
     // single tiles win -- balance across the XCDs matters more than sharing brick rows in one
@@ -121,11 +121,11 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
         const int ly0 = (int)(ty * tile_h);
         const int pr[3] = {globalRow(P, ly0), globalRow(P, ly0 + (int)tile_h / 2), globalRow(P, ly0 + (int)tile_h - 1)};
         for (unsigned tx = 0; tx < tiles_x; tx++) {
-            const double x0 = tx * (double)kFastTileW;
+            const double x0 = tx * (double)tile_w;
             double wmax = 0.0;
             for (int r = 0; r < 3; r++)
                 for (int k = 0; k < 3; k++) {
-                    const double px = std::min(x0 + k * ((double)kFastTileW - 1.0) / 2.0, (double)P.img_w - 1.0) + 0.5;
+                    const double px = std::min(x0 + k * ((double)tile_w - 1.0) / 2.0, (double)P.img_w - 1.0) + 0.5;
                     const double py = std::min((double)pr[r], (double)P.img_h - 1.0) + 0.5;
                     wmax = std::max(wmax, raySamples(P, px, py));
                 }

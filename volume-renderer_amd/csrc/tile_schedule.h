@@ -21,8 +21,10 @@ constexpr uint32_t kTilePadding = 0xffffffffu;
 // table[b] = tile_x | tile_y << 16 for block b, kTilePadding for padding blocks.
 // `rows` = local image rows of this launch (stripe padding included).
 // returns the number of tiles with a non-zero work estimate (*max_ray_samples: the longest ray's expected sample count)
-// tile_h: rows per tile (kFastTileH, or 32 for the staged trilinear kernel's 16-wavefront workgroups)
-unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples = nullptr, unsigned tile_h = kFastTileH);
+// tile_h / tile_w: rows / columns per tile (kFastTileH x kFastTileW; the staged trilinear kernel also runs 32x32-pixel tiles on
+// 16-wavefront workgroups and 16x32-pixel ones)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples = nullptr, unsigned tile_h = kFastTileH,
+                           unsigned tile_w = kFastTileW);
 
 // how close the view is to a volume axis: |largest component| of the central ray's direction in voxel units, 1 = along
 // an axis, 0.58 = along the space diagonal.  Launch heuristics only (RendererCore::prepareLaunch).

@@ -72,10 +72,10 @@ constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of t
 constexpr int TS_FB_BATCH = 4;                            // samples whose taps a tile that is not staged requests together (six or eight: no faster)
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
 
-template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM>
+template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM, int TW = 4>
 struct TslabCfg {
-    static constexpr int THREADS = 64 * NW;                                       // 4 x NW/4 wavefronts of 8x8 pixels
-    static constexpr int TILE_H = 8 * (NW / 4);
+    static constexpr int THREADS = 64 * NW;                                       // TW x NW/TW wavefronts of 8x8 pixels
+    static constexpr int TILE_W = 8 * TW, TILE_H = 8 * (NW / TW);
     static constexpr int WAVES_PER_SIMD = (LDSKB <= 80 ? 2 : 1) * NW / 4;
     static constexpr int BRICK_BYTES = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // a brick of the apron copies: 80 B (u8) / 160 B (u16)
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
@@ -108,8 +108,10 @@ struct TslabCfg {
 
 // PERM: per-major-axis apron copies (src = order 0, src_y = order 1, src_x = order 2), the tap pair along the first minor axis,
 // layer thickness 4 or 2 per tile; otherwise the order-0 copy for every tile, pairs along x, whole layers
-template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB, bool PERM>
-__global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
+// TW: wavefronts per tile row -- 4: 32x16-pixel tiles (32x32 with 16 wavefronts); 2: 16x32-pixel tiles, whose brick rectangles are
+// a fifth smaller where the view's shear runs along the image's x direction (views near a body diagonal of the volume)
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB, bool PERM, int TW = 4>
+__global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, TW>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
                                                                        const VoxelT *__restrict__ vol,
                                                                        const uint8_t *__restrict__ src,
                                                                        const uint8_t *__restrict__ src_y,
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
                                                                        const uint32_t *__restrict__ tile_table,
                                                                        const int no_stage)
 {
-    using C = TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>;
+    using C = TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, TW>;
     constexpr int TS_NW = NW, TS_THREADS = C::THREADS;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
     VR_TSLAB_STAT(const uint64_t st_entry = clock64();)
     const unsigned tx = t & 0xffffu, ty = t >> 16;
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const int lx = (int)(tx * kFastTileW + (wave & 3u) * 8u + (lane & 7u));
-    const int ly = (int)(ty * (unsigned)C::TILE_H + (wave >> 2) * 8u + (lane >> 3));
+    const int lx = (int)(tx * (unsigned)C::TILE_W + (wave % (unsigned)TW) * 8u + (lane & 7u));
+    const int ly = (int)(ty * (unsigned)C::TILE_H + (wave / (unsigned)TW) * 8u + (lane >> 3));
     int px = lx, py;
     if (P.stripe_count > 1) {
         const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
 
     // ================================================================== the tile's load plan
     // corner rays in voxel coordinates: line E + t * G
-    const bool is_corner = (wave == 0 && lane == 0) || (wave == 3 && lane == 7) || (wave == NW - 4 && lane == 56) || (wave == NW - 1 && lane == 63);
+    const bool is_corner = (wave == 0 && lane == 0) || (wave == TW - 1 && lane == 7) || (wave == NW - TW && lane == 56) || (wave == NW - 1 && lane == 63);
     if (is_corner) {
-        const int cidx = (wave >= NW - 4 ? 2 : 0) + ((wave & 3u) == 3u ? 1 : 0);
+        const int cidx = (wave >= NW - TW ? 2 : 0) + ((wave % (unsigned)TW) == (unsigned)(TW - 1) ? 1 : 0);
         float ex, ey, ez, gx, gy, gz;
         voxel_float(ray.ox, ray.oy, ray.oz, ex, ey, ez);
         voxel_float(ray.ox + ray.dx, ray.oy + ray.dy, ray.oz + ray.dz, gx, gy, gz);
@@ -861,32 +863,32 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM>::
 }
 
 // ------------------------------------------------------------------ dispatch
-// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 4: u16 (below)
-template <typename VoxelT, int NW, int LDSKB, bool PERM, int DIVTC, int VIEW, bool POW2, int MODE>
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 5: u16 (below)
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
 {
-    const uint32_t *table = NW == 16 ? L.tile_table32 : L.tile_table;
-    const uint32_t blocks = NW == 16 ? L.tile_table32_blocks : L.tile_table_blocks;
+    const uint32_t *table = NW == 16 ? L.tile_table32 : (TW == 2 ? L.tile_table_tall : L.tile_table);
+    const uint32_t blocks = NW == 16 ? L.tile_table32_blocks : (TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks);
     int no_stage = L.tri_slab == 2 ? 1 : 0;
     VR_TSLAB_CHK(if (std::getenv("VR_TSLAB_SABOTAGE") != nullptr) no_stage = 3;)   // checked build only: the plan guard's negative control
-    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM>), dim3(blocks), dim3(64 * NW), 0, st, P,
+    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM, TW>), dim3(blocks), dim3(64 * NW), 0, st, P,
                        (const VoxelT *)vol, (const uint8_t *)L.apron, (const uint8_t *)L.apron_y, (const uint8_t *)L.apron_x, tf, fb, spp, table,
                        no_stage);
     return hipGetLastError();
 }
 
-template <typename VoxelT, int NW, int LDSKB, bool PERM, int VIEW, int MODE>
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int VIEW, int MODE>
 static hipError_t dispatch_tslab3(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                   uint32_t *spp, hipStream_t st)
 {
     const bool pow2 = L.pow2_dims != 0 && L.divmode_tc == DIV_UNIT;
-    if (L.divmode_tc == DIV_CERT) return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_CERT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
-    if (pow2) return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_UNIT, VIEW, true, MODE>(P, L, vol, tf, fb, spp, st);
-    return launch_tslab<VoxelT, NW, LDSKB, PERM, DIV_UNIT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+    if (L.divmode_tc == DIV_CERT) return launch_tslab<VoxelT, NW, LDSKB, PERM, TW, DIV_CERT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
+    if (pow2) return launch_tslab<VoxelT, NW, LDSKB, PERM, TW, DIV_UNIT, VIEW, true, MODE>(P, L, vol, tf, fb, spp, st);
+    return launch_tslab<VoxelT, NW, LDSKB, PERM, TW, DIV_UNIT, VIEW, false, MODE>(P, L, vol, tf, fb, spp, st);
 }
 
-template <typename VoxelT, int NW, int LDSKB, bool PERM>
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW = 4>
 static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                  uint32_t *spp, hipStream_t st)
 {
@@ -894,10 +896,10 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
     const int mode = (L.mip ? 1 : 0) + (P.tf_len > 1 ? 2 : 0);
 #define VR_TSLAB_M(VW)                                                                                         \
     switch (mode) {                                                                                            \
-    case 0: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 0>(P, L, vol, tf, fb, spp, st);                \
-    case 1: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 1>(P, L, vol, tf, fb, spp, st);                \
-    case 2: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 2>(P, L, vol, tf, fb, spp, st);                \
-    default: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, VW, 3>(P, L, vol, tf, fb, spp, st);               \
+    case 0: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, TW, VW, 0>(P, L, vol, tf, fb, spp, st);                \
+    case 1: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, TW, VW, 1>(P, L, vol, tf, fb, spp, st);                \
+    case 2: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, TW, VW, 2>(P, L, vol, tf, fb, spp, st);                \
+    default: return dispatch_tslab3<VoxelT, NW, LDSKB, PERM, TW, VW, 3>(P, L, vol, tf, fb, spp, st);               \
     }
     if (view == 0) { VR_TSLAB_M(0) }
     if (view == 1) { VR_TSLAB_M(1) }
@@ -911,11 +913,13 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
 //   tri_slab 3: the same with the per-axis copies, layer thickness per tile (half layers where whole ones do not fit)
 //   tri_slab 4: 32x32 tiles, 16 wavefronts, a CU's whole LDS, per-axis copies, thickness per tile
 //   tri_slab 5: 32x16 tiles on a CU's whole LDS, per-axis copies, thickness per tile
+//   tri_slab 6: tri_slab 3 on 16x32-pixel tiles (two wavefronts wide, four tall)
 // (round 4 also measured the whole-LDS shapes with whole layers only: 32x16 tiles 1.96-2.13 ms over the orbit poses, 32x32
 // tiles 1.64-3.6 ms -- behind the half-layer shapes at every pose, not kept)
 hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS);
 
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
@@ -930,6 +934,7 @@ hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
     if (L.tri_slab == 3 && perm_ok) return launch_tslab_u16_half(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 4 && perm_ok && t32) return launch_tslab_u16_half16(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 5 && perm_ok) return launch_tslab_u16_halfwide(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 6 && perm_ok && L.tile_table_tall != nullptr) return launch_tslab_u16_halftall(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint16_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -941,6 +946,9 @@ hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS) { return dispatch_tslab<uint16
 #endif
 #if VR_TSLAB_TU == 4 || VR_TSLAB_TU == -1
 hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 160, true>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 5 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 80, true, 2>(P, L, vol, tf, fb, spp, st); }
 #endif
 
 }  // namespace vr
