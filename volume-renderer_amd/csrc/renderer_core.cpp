@@ -754,7 +754,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
 {
     tune_measure_ = false;
     tuneCollect();
-    const int prior = (L.sparse_shard ? 1 : 0) | (L.pipelined ? 2 : 0) | (L.short_batches ? 4 : 0) | (L.tri_slab << 3);
+    const int prior = L.filter == 1 ? (L.tri_slab << 3) : ((L.sparse_shard ? 1 : 0) | (L.pipelined ? 2 : 0) | (L.short_batches ? 4 : 0));
     last_choice_ = prior;
     if (!autotune || force_generic != 0 || !L.tile_table) return;
     // candidates, the heuristic's choice (what buildFrame / refreshTileSchedule left in L) first
@@ -768,7 +768,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         if (relay_ok) add(1);
     } else if (L.filter == 1 && L.apron != nullptr && tri_slab_candidate(P, L)) {
         // TRILINEAR: the LDS-staged kernel in its shapes, the batched kernel where it can run
-        add(prior & ~7);
+        add(prior);
         add(1 << 3);
         if (tri_path_candidate(P, L)) add(0);
         if (L.apron_y != nullptr && L.apron_x != nullptr) {
@@ -776,6 +776,8 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
             if (L.tile_table32 != nullptr) add(4 << 3);
             add(5 << 3);
             if (L.tile_table_tall != nullptr) add(6 << 3);
+        } else if (L.bytes_per_voxel == 1 && L.tile_table_tall != nullptr && viewAxisAlignment(P) < 0.92) {
+            add(6 << 3);                                                 // 8-bit volumes, oblique views: whole layers on 16x32-pixel tiles
         }
     }
     if (n < 2) return;
@@ -1044,7 +1046,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     const uint64_t shape_key = tileScheduleKey(P, rows, false);
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
-    const bool need32 = filter == 1 && res_bytes_ == 2 && tri_slab_candidate(P, L);   // 32x32-pixel tiles for the staged trilinear kernel's 16-wavefront workgroups
+    const bool need32 = filter == 1 && tri_slab_candidate(P, L);   // 32x32- and 16x32-pixel tiles for the staged trilinear kernel's other shapes
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table32_blocks_ == 0)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);

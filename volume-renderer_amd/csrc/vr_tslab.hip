@@ -863,7 +863,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
 }
 
 // ------------------------------------------------------------------ dispatch
-// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 5: u16 (below)
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 5: u16 (below); 6: u8 on 16x32-pixel tiles
 template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
@@ -920,12 +920,20 @@ hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);          // 8-bit volumes: whole layers on 16x32-pixel tiles (tri_slab 6)
 
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
 #endif
 #if VR_TSLAB_TU == 0 || VR_TSLAB_TU == -1
-hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st); }
+hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS)
+{
+    if (L.tri_slab == 6 && L.tile_table_tall != nullptr) return launch_tslab_u8_tall(P, L, vol, tf, fb, spp, st);
+    return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
+}
+#endif
+#if VR_TSLAB_TU == 6 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false, 2>(P, L, vol, tf, fb, spp, st); }
 #endif
 #if VR_TSLAB_TU == 1 || VR_TSLAB_TU == -1
 hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
