@@ -1091,15 +1091,15 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // workgroups per CU -- when the view is aligned with a volume axis (cfg3 default pose: every tile staged, 1.25 vs 1.93 ms on
     // the batched kernel) and for 8-bit volumes at every pose (80-byte slots: orbit poses 1.1-1.4 ms against 2.1).  A 16-bit
     // volume's oblique layers do not fit three deep (240-400 bricks of 160 B): those views take the per-axis copies and half
-    // layers (round 4: orbit poses 1.43-1.62 ms against 2.9-3.4 whole-layer / 2.6-3.0 batched), on a CU's whole LDS when the
-    // view runs near a body diagonal of the volume (2.47 ms against 2.9).
+    // layers (round 4: orbit poses 1.43-1.62 ms against 2.9-3.4 whole-layer / 2.6-3.0 batched), on 16x32-pixel tiles with the
+    // ring's rows holding their own brick ranges when the view runs near a body diagonal of the volume (1.68 ms against 3.0).
     if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L)) {
         if (aligned || L.bytes_per_voxel == 1) {
             L.tri_slab = 1;
         } else {
             double r1, r2;
             viewAxisRatios(P, r1, r2);
-            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 5 : 3;
+            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 6 : 3;
         }
     }
     // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is

@@ -123,6 +123,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                                                                        const int no_stage)
 {
     using C = TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, TW>;
+    // rows (the ring's rows with their own brick ranges, below): compiled into the 16x32-pixel shapes only -- the views that need rows are
+    // the ones those tiles suit, and the other shapes keep their leaner phase loop (with the rows' loader and table producer compiled in,
+    // tiles that never use them run 2-4 % slower: measured on every shape)
+    constexpr bool ROWS = TW == 2;
     constexpr int TS_NW = NW, TS_THREADS = C::THREADS;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
@@ -369,14 +373,34 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     int c_first = 0, c_last = 0, kmax = 0, n_phases = 0, L0 = 0, Llo = 0, Lhi = -1, plan_bytes = 0;
     bool any_prefix = false;
     float delta = 0.0f;
-    uint2 *plan = nullptr;
+    uint8_t *plan_b = nullptr;                                           // plan entry of layer L at plan_b + (L - Llo) * plan_stride
+    int plan_stride = 8;
+    // ROWS (round 4, last): the ring's rows (along b) may hold their own brick ranges instead of the rectangle's -- what a view
+    // near a body diagonal needs, where a tile's footprint is a slanted band and its bounding rectangle half empty.  The band
+    // is one strip  c1 <= a + strip_k * b <= c2  per layer (c1, c2: support of the footprint's eight corner points) intersected
+    // with the rectangle; strip_k is the tile's (direction of the footprint's longest side, chosen on its farthest layer).
+    bool use_strip = false, try_rows = false;
+    float strip_k = 0.0f;
+    int rowtab_off = 0;
+    // brick range [alo, alo + w) of brick row r of a layer whose band is c1 <= a + strip_k * b <= c2 inside bricks lo_a .. hi_a:
+    // the taps of row r come from positions with b in [4 r - mrg, 4 r + 4 + mrg]
+    auto strip_row = [&](float c1, float c2, int lo_a, int hi_a, int r, int &alo, int &w) {
+        const float mrg = 0.5f + delta;
+        const float y0 = (float)(4 * r) - mrg, y1 = (float)(4 * r + 4) + mrg;
+        const float k0 = strip_k * y0, k1 = strip_k * y1;
+        const float a_lo = c1 - fmaxf(k0, k1), a_hi = c2 - fminf(k0, k1);
+        const float big = 1.0e9f;
+        alo = clampi((int)floorf(fmaxf(fminf(a_lo - mrg, big), -big)) >> 2, lo_a, hi_a);
+        const int ahi = clampi((int)floorf(fmaxf(fminf(a_hi + mrg, big), -big)) >> 2, lo_a, hi_a);
+        w = max(ahi - alo + 1, 1);
+    };
     int RA = 1, RB = 1, ia_lo = 0, ib_lo = 0, im_lo = 0, na_e = 0, nb_e = 0, nm_e = 0, taba_bytes = 0, tabb_bytes = 0, head_bytes = 0, slots_avail = 0;
     bool fits = false;
     VR_TSLAB_STAT(unsigned st_reason = 0;)
     for (;;) {
         const int T = 1 << LSH;
         const int nlay_m = nbr_m << (2 - LSH);                           // layers along the major axis
-        if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; red[6] = 0x7fffffff; red[7] = -1; red[8] = 0x7fffffff; red[9] = -1; }
+        if (threadIdx.x == 0) { red[0] = 0x7fffffff; red[1] = -0x7fffffff; red[2] = 0; red[3] = 0; red[4] = 0; red[5] = 0; red[6] = 0x7fffffff; red[7] = -1; red[8] = 0x7fffffff; red[9] = -1; red[10] = 0; }
         __syncthreads();
         // layer (along m) of the cell a position's taps start in: floor(max(f_m - 0.5, 0)) >> LSH
         auto layer_of = [&](float fm) -> int { return min((int)fmaxf(fm - 0.5f, 0.0f), ndim_m - 1) >> LSH; };
@@ -415,22 +439,59 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         // major axis (ring base + layer slot + plane); they are addressed through virtual bases (real base - first index).
         Llo = max(sgn > 0 ? c_first - 1 : -(c_last + 3), 0); Lhi = min(sgn > 0 ? c_last + 3 : -(c_first - 1), nlay_m - 1);
         const int n_plan = max(Lhi - Llo + 1, 0);
-        plan_bytes = (n_plan * 8 + 15) & ~15;
-        plan = reinterpret_cast<uint2 *>(ring) - Llo;                    // plan[L] for Llo <= L <= Lhi
+        const float mrg = 0.5f + delta;                                  // taps: voxels floor(f - 0.5) and + 1 per axis
+        // the corner rays' crossings of the two planes bounding layer L's samples: (a, b) of corner c at plane 0 / 1
+        auto layer_points = [&](int L, float (&pa)[8], float (&pb)[8]) {
+            const float c_lo = (float)(T * L) - 0.5f - delta, c_hi = (float)(T * L + T) + 0.5f + delta;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]), ga = sel3(ax_a, G[c][0], G[c][1], G[c][2]), gb = sel3(ax_b, G[c][0], G[c][1], G[c][2]);
+                const float em = sel3(ax_m, E[0], E[1], E[2]), ea = sel3(ax_a, E[0], E[1], E[2]), eb = sel3(ax_b, E[0], E[1], E[2]);
+                const float t1 = (c_lo - em) / gm, t2 = (c_hi - em) / gm;
+                pa[c] = ea + t1 * ga; pa[c + 4] = ea + t2 * ga; pb[c] = eb + t1 * gb; pb[c + 4] = eb + t2 * gb;
+            }
+        };
+        // ---- rows or rectangles?  On the tile's farthest layer (footprints grow with the distance from the eye): the widest row
+        // of the band along each of the footprint's three directions (tile edge x, tile edge y, the rays' sweep across the layer)
+        // against the rectangle's width; rows when they save 15 % of the slots.  Only tried when rectangles have failed (try_rows):
+        // a tile that fits as rectangles keeps the cheaper loader
+        use_strip = false; strip_k = 0.0f;
+        if (ROWS && try_rows && stage && any_prefix && n_plan > 0) {
+            const float em = sel3(ax_m, E[0], E[1], E[2]);
+            const int Lf = fabsf((float)(T * Lhi) - em) >= fabsf((float)(T * Llo) - em) ? Lhi : Llo;
+            float pa[8], pb[8];
+            layer_points(Lf, pa, pb);
+            float amin = pa[0], amax = pa[0], bmin = pb[0], bmax = pb[0];
+#pragma unroll
+            for (int q = 1; q < 8; q++) { amin = fminf(amin, pa[q]); amax = fmaxf(amax, pa[q]); bmin = fminf(bmin, pb[q]); bmax = fmaxf(bmax, pb[q]); }
+            const float w_rect = (amax - amin + 2.0f * mrg) * 0.25f + 1.25f, n_rows = (bmax - bmin + 2.0f * mrg) * 0.25f + 1.25f;
+            const float va[3] = {pa[1] - pa[0], pa[2] - pa[0], pa[4] - pa[0]}, vb[3] = {pb[1] - pb[0], pb[2] - pb[0], pb[4] - pb[0]};
+            float w_best = w_rect;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                if (!(fabsf(vb[d]) * 8.0f > fabsf(va[d])) || !(fabsf(vb[d]) > 1.0e-3f)) continue;       // band nearly parallel to the rows: no use
+                const float k = -va[d] / vb[d];
+                float c1 = pa[0] + k * pb[0], c2 = c1;
+#pragma unroll
+                for (int q = 1; q < 8; q++) { const float cc = pa[q] + k * pb[q]; c1 = fminf(c1, cc); c2 = fmaxf(c2, cc); }
+                const float w = ((c2 - c1) + fabsf(k) * (4.0f + 2.0f * mrg) + 2.0f * mrg) * 0.25f + 1.25f;
+                if (w < w_best) { w_best = w; strip_k = k; }
+            }
+            use_strip = w_best <= 0.85f * w_rect && n_rows <= 30.0f;
+            if (!use_strip) strip_k = 0.0f;
+        }
+        plan_stride = (ROWS && use_strip) ? 16 : 8;
+        plan_bytes = (n_plan * plan_stride + 15) & ~15;
+        plan_b = ring - (ptrdiff_t)Llo * plan_stride;                    // plan entry of layer L (Llo <= L <= Lhi) at plan_b + L * plan_stride
         if (stage && any_prefix && plan_bytes <= C::REGION / 2) {
+            int m_bb = 0;                                                // widest bounding rectangle (its extent must fit the entry's 8 bits)
             int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1, m_low = 0;
             for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
-                const float c_lo = (float)(T * L) - 0.5f - delta, c_hi = (float)(T * L + T) + 0.5f + delta;
-                float amin = __builtin_inff(), amax = -__builtin_inff(), bmin = __builtin_inff(), bmax = -__builtin_inff();
+                float pa[8], pb[8];
+                layer_points(L, pa, pb);
+                float amin = pa[0], amax = pa[0], bmin = pb[0], bmax = pb[0];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float gm = sel3(ax_m, G[c][0], G[c][1], G[c][2]), ga = sel3(ax_a, G[c][0], G[c][1], G[c][2]), gb = sel3(ax_b, G[c][0], G[c][1], G[c][2]);
-                    const float em = sel3(ax_m, E[0], E[1], E[2]), ea = sel3(ax_a, E[0], E[1], E[2]), eb = sel3(ax_b, E[0], E[1], E[2]);
-                    const float t1 = (c_lo - em) / gm, t2 = (c_hi - em) / gm;
-                    const float a1 = ea + t1 * ga, a2 = ea + t2 * ga, b1 = eb + t1 * gb, b2 = eb + t2 * gb;
-                    amin = fminf(amin, fminf(a1, a2)); amax = fmaxf(amax, fmaxf(a1, a2));
-                    bmin = fminf(bmin, fminf(b1, b2)); bmax = fmaxf(bmax, fmaxf(b1, b2));
-                }
+                for (int q = 1; q < 8; q++) { amin = fminf(amin, pa[q]); amax = fmaxf(amax, pa[q]); bmin = fminf(bmin, pb[q]); bmax = fmaxf(bmax, pb[q]); }
                 // taps: voxels floor(f - 0.5) and + 1 per axis
                 const float big = 1.0e9f;
                 int lo_a = clampi((int)floorf(fmaxf(fminf(amin - 0.5f - delta, big), -big)) >> 2, 0, nbr_a - 1);
@@ -440,15 +501,28 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                 // (the guard's negative control, checked build only: every rectangle one brick short on each side, still well-formed)
                 VR_TSLAB_CHK(if (no_stage == 3) { lo_a = min(lo_a + 1, hi_a); hi_a = max(hi_a - 1, lo_a); lo_b = min(lo_b + 1, hi_b); hi_b = max(hi_b - 1, lo_b); })
                 const int dda = hi_a - lo_a, ddb = hi_b - lo_b;
-                plan[L] = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
-                m_dda = max(m_dda, dda); m_ddb = max(m_ddb, ddb);        // every planned layer is one some phase reads or prefetches
+                const uint2 e01 = make_uint2((uint32_t)lo_a | ((uint32_t)lo_b << 16), (uint32_t)min(dda, 255) | ((uint32_t)min(ddb, 255) << 8));
+                int width = dda;                                         // widest row of the layer - 1
+                if (ROWS && use_strip) {
+                    float c1 = pa[0] + strip_k * pb[0], c2 = c1;
+#pragma unroll
+                    for (int q = 1; q < 8; q++) { const float cc = pa[q] + strip_k * pb[q]; c1 = fminf(c1, cc); c2 = fmaxf(c2, cc); }
+                    c1 -= 0.03125f; c2 += 0.03125f;                      // (rounding of the products: far below 1/32 voxel)
+                    width = 0;
+                    for (int r = lo_b; r <= hi_b; r++) { int alo, w; strip_row(c1, c2, lo_a, hi_a, r, alo, w); width = max(width, w - 1); }
+                    *reinterpret_cast<uint4 *>(plan_b + (ptrdiff_t)L * 16) = make_uint4(e01.x, e01.y, __float_as_uint(c1), __float_as_uint(c2));
+                } else {
+                    *reinterpret_cast<uint2 *>(plan_b + (ptrdiff_t)L * 8) = e01;
+                }
+                m_bb = max(m_bb, dda);
+                m_dda = max(m_dda, width); m_ddb = max(m_ddb, ddb);      // every planned layer is one some phase reads or prefetches
                 m_loa = min(m_loa, lo_a); m_hia = max(m_hia, hi_a); m_lob = min(m_lob, lo_b); m_hib = max(m_hib, hi_b);
                 if (amin - delta < 1.0f || bmin - delta < 1.0f) m_low = 1;   // some ray comes within a voxel of a low face
             }
-            m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low);
+            m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low); m_bb = wave_max_i(m_bb);
             m_loa = wave_min_i(m_loa); m_hia = wave_max_i(m_hia); m_lob = wave_min_i(m_lob); m_hib = wave_max_i(m_hib);
             if (lane == 0) {
-                atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low);
+                atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low); atomicMax(&red[10], m_bb);
                 atomicMin(&red[6], m_loa); atomicMax(&red[7], m_hia); atomicMin(&red[8], m_lob); atomicMax(&red[9], m_hib);
             }
         }
@@ -466,14 +540,20 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         taba_bytes = (na_e * 2 + 3) & ~3; tabb_bytes = (nb_e * 2 + 3) & ~3;
         const int tabm_bytes = nm_e * 4;
         // (the ring starts on a 256-byte boundary: the 1-KiB DMA pieces then land on whole LDS rows, 1 % on the 1024^3 workload)
-        head_bytes = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 255) & ~255;
+        // (rows: four row tables of 32 entries of 8 bytes behind the torus tables, one per layer in flight)
+        rowtab_off = (plan_bytes + taba_bytes + tabb_bytes + tabm_bytes + 7) & ~7;
+        head_bytes = (rowtab_off + ((ROWS && use_strip) ? 4 * 32 * 8 : 0) + 255) & ~255;
         slot_b = C::BRICK_BYTES >> (2 - LSH);
         slots_avail = (C::REGION - head_bytes) / slot_b;
         const int layer_slots_max = C::MAX_PIECES * TS_THREADS / (slot_b / 16);
-        fits = head_bytes <= C::REGION / 2 && !(RA * RB > layer_slots_max || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * slot_b > 65535);
+        fits = head_bytes <= C::REGION / 2 && !(RA * RB > layer_slots_max || RA * RB * 3 > slots_avail || RA > 255 || RB > 255 || RA * RB * slot_b > 65535) &&
+               uniform_i(red[10]) <= 255 && (!use_strip || RB <= 32);
         VR_TSLAB_STAT(st_reason = !stage ? 1u : (RA * RB > layer_slots_max ? 2u : (RA * RB * 3 > slots_avail ? 3u : (RA * RB * slot_b > 65535 ? 4u : 0u)));)
-        if (fits || !stage || !any_prefix || !C::HALF_OK || LSH == 1) break;
-        LSH = 1;                                                         // once more with half layers
+        // the attempts: whole layers as rectangles; half layers as rectangles (instances with per-axis copies); the thinnest as rows
+        if (fits || !stage || !any_prefix || try_rows) break;
+        if (C::HALF_OK && LSH == 2) LSH = 1;                             // once more with half layers
+        else if (ROWS) try_rows = true;                                  // once more with rows
+        else break;
         __syncthreads();                                                 // (every thread has read red[] before it is reset)
     }
     if (!fits) stage = false;
@@ -499,13 +579,14 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // the wrap-around terms: a torus column / row below the rectangle's origin holds the brick one ring further
     const uint32_t wrap_a = (uint32_t)RA * sA * (uint32_t)C::BRICK_BYTES, wrap_b = (uint32_t)RB * sB * (uint32_t)C::BRICK_BYTES;
     // (relative offsets are 32-bit: (RA + 1) * sA + (RB + 1) * sB bricks must stay below 2^31 bytes -- any volume a GPU holds)
-    if ((uint64_t)(RA + 1) * (uint64_t)sA * (uint64_t)C::BRICK_BYTES + (uint64_t)(RB + 1) * (uint64_t)sB * (uint64_t)C::BRICK_BYTES >= (1ull << 31)) stage = false;
+    if ((uint64_t)(RA + 257) * (uint64_t)sA * (uint64_t)C::BRICK_BYTES + (uint64_t)(RB + 1) * (uint64_t)sB * (uint64_t)C::BRICK_BYTES >= (1ull << 31)) stage = false;
     if (stage && any_prefix) {
         // torus position of every layer's rectangle origin (second word of the plan entries)
         for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
-            uint2 e = plan[L];
+            uint2 *pe = reinterpret_cast<uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
+            uint2 e = *pe;
             e.y |= ((e.x & 0xffffu) % (uint32_t)RA) << 16 | ((e.x >> 16) % (uint32_t)RB) << 24;
-            plan[L] = e;
+            *pe = e;
         }
         // torus tables: N + 1 entries per axis (the last one repeats voxel N - 1: the + 1 tap of the last cell is the
         // clamped one): byte offset of the slot of brick (i >> 2) mod R + of the position inside the 5x4x4 apron brick
@@ -544,9 +625,25 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ.  Per lane and piece: two wrap-around tests
     // (is this lane's torus column / row below the rectangle's torus origin?), two extent tests, two masked adds -- the layer's
     // base address (source copy + the brick of torus origin (0, 0) + the half of the brick) is scalar arithmetic
+    uint2 *const rowtab = reinterpret_cast<uint2 *>(ring + rowtab_off);
+    // rows: the table of layer L -- per brick row r of its rectangle the row's own brick range, as (byte offset of the row's
+    // torus origin relative to the layer's, torus column of its first brick | number of bricks << 8).  Written by the lanes of
+    // ONE wavefront a phase before the layer is requested (the phase's barrier publishes it)
+    auto make_rows = [&](int L) {
+        if (L < Llo || L > Lhi) return;
+        const uint4 e = *reinterpret_cast<const uint4 *>(plan_b + (ptrdiff_t)L * 16);
+        const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)(e.x >> 16), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u), la = (int)((e.y >> 16) & 255u);
+        if ((int)lane <= ddb && lane < 32u) {
+            int alo, w;
+            strip_row(__uint_as_float(e.z), __uint_as_float(e.w), lo_a, lo_a + dda, lo_b + (int)lane, alo, w);
+            const int la_row = alo % RA;
+            const uint32_t rowbase = (uint32_t)((alo - la_row) - (lo_a - la)) * sA * (uint32_t)C::BRICK_BYTES;     // a multiple of RA bricks, >= 0
+            rowtab[(L & 3) * 32 + (int)lane] = make_uint2(rowbase, (uint32_t)la_row | ((uint32_t)w << 8));
+        }
+    };
     auto issue_layer = [&](int L) {
         if (L < Llo || L > Lhi) return;
-        const uint2 e = plan[L];
+        const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
         const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
         const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
         const int dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u), la = (int)((ey >> 16) & 255u), lb = (int)(ey >> 24);
@@ -555,6 +652,26 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         const uint64_t origin = (uint64_t)(uint32_t)(lo_a - la) * sA + (uint64_t)(uint32_t)(lo_b - lb) * sB + (uint64_t)(uint32_t)(L >> (2 - LSH)) * sM;
         const uint8_t *const base = src_m + origin * (uint64_t)C::BRICK_BYTES + (LSH == 1 ? (uint64_t)(L & 1) * (uint64_t)(C::BRICK_BYTES / 2) : 0ull);
         const uint32_t dst = ring_base + (uint32_t)lz * layer_bytes + (uint32_t)wave * 1024u;
+        if (ROWS && use_strip) {
+            // rows: this lane's row tells where its bricks start on the torus and how many there are
+            // (all row entries first, then the requests: the LDS round trips overlap)
+            uint2 re[C::MAX_PIECES];
+            int obs[C::MAX_PIECES], mbs[C::MAX_PIECES];
+#pragma unroll
+            for (int q = 0; q < C::MAX_PIECES; q++) {
+                const int db_ = ld_tb[q] - lb;
+                mbs[q] = db_ >> 31; obs[q] = db_ + (mbs[q] & RB);
+                re[q] = rowtab[(L & 3) * 32 + (obs[q] & 31)];
+            }
+#pragma unroll
+            for (int q = 0; q < C::MAX_PIECES; q++) {
+                if (q >= pieces) break;
+                const int da_ = ld_ta[q] - (int)(re[q].y & 255u), ma = da_ >> 31, oa = da_ + (ma & RA);
+                if (obs[q] <= ddb && obs[q] >= 0 && oa < (int)(re[q].y >> 8))
+                    glds16_rel(base, ld_rel[q] + ((uint32_t)ma & wrap_a) + ((uint32_t)mbs[q] & wrap_b) + re[q].x, dst + (uint32_t)(q * TS_NW) * 1024u);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < C::MAX_PIECES; q++) {
             if (q >= pieces) break;
@@ -575,6 +692,11 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         constexpr int M = decltype(m_tag)::value, A = M == 0 ? 1 : 0;          // minor axes: A and the other one
         constexpr int PA = PERM ? A : 0, O1 = PA == 0 ? 1 : 0, O2 = 2;         // the other two voxel axes, in x-y-z order
         // ---- prologue: the layers phases 0 .. LA-1 read
+        if (ROWS && use_strip) {                                         // rows: the tables of the prologue's layers and of the one phase 0 requests, a wavefront each
+            const int first = sgn > 0 ? L0 : L0 + 1 - LA - 1;                // (sgn > 0: L0 .. L0 + LA + 1; else L0 - LA .. L0 + 1)
+            if ((int)wave < LA + 2) make_rows(first + (int)wave);
+            __syncthreads();
+        }
         if (sgn > 0) { for (int l = 0; l <= LA; l++) issue_layer(L0 + l); }
         else { for (int l = 1; l >= 1 - LA; l--) issue_layer(L0 + l); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -613,10 +735,16 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     // resident in phase L: L and the layer above it (the + 1 taps), one more in the marching direction when the ring is four deep
                     const int lo_res = sgn > 0 ? L : L - (LA >= 2 ? 1 : 0), hi_res = sgn > 0 ? L + 1 + (LA >= 2 ? 1 : 0) : L + 1;
                     if (lyr < lo_res || lyr > hi_res || lyr < Llo || lyr > Lhi) { bad++; continue; }
-                    const uint2 e = plan[lyr];
+                    const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)lyr * plan_stride);
                     const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)(e.x >> 16), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u);
                     const int ba = ia >> 2, bb = jb >> 2;
-                    if (ba < lo_a || ba > lo_a + dda || bb < lo_b || bb > lo_b + ddb) bad++;
+                    if (ba < lo_a || ba > lo_a + dda || bb < lo_b || bb > lo_b + ddb) { bad++; continue; }
+                    if (ROWS && use_strip) {                             // rows: inside the row's own range (what make_rows had loaded)
+                        const uint4 e4 = *reinterpret_cast<const uint4 *>(plan_b + (ptrdiff_t)lyr * 16);
+                        int alo, w;
+                        strip_row(__uint_as_float(e4.z), __uint_as_float(e4.w), lo_a, lo_a + dda, bb, alo, w);
+                        if (ba < alo || ba >= alo + w) bad++;
+                    }
                     if (ia < 0 || ia > ndim_a - 1 || ib < 0 || im < 0) bad++;
                 }
             return bad;
@@ -653,6 +781,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             const int L = L0 + sgn * p, Lnext = L + sgn;
             // the layer that phase p + LA reads first
             issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
+            if (ROWS && use_strip && (int)wave == (p & (TS_NW - 1))) make_rows(sgn > 0 ? L + LA + 2 : L - LA - 1);   // rows: the table of the layer the NEXT phase requests
             // ---- this phase's samples: the ones whose cell lies in layer L.  The body is straight-line code for the whole
             // wavefront: a lane without a sample in this layer reads taps at its (valid, unchanged) prepared addresses and
             // drops the result -- exec-mask branches around the body cost more scalar instructions than the arithmetic
