@@ -159,11 +159,12 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    sample; every mode incl. the transfer function; volumes beyond 4 GiB) wherever it is eligible,
    7 = that kernel with staging switched off: every tile takes the path of tiles whose brick layers do not fit LDS
    (pair loads from the apron copy, four samples' taps in flight) -- the cross-check of that path,
-   8 / 9 / 10 / 11 = (16-bit volumes; 8-bit ones run as under 6) the LDS-staged kernel with one apron copy per major axis and the
-   layer thickness chosen per tile -- whole brick layers where three of them fit the ring, half layers (two voxels, 80-byte
-   slots) where they do not, i.e. at views oblique to the volume axes -- on 32x16-pixel tiles with two workgroups per CU (8),
-   on 32x32-pixel tiles with 16 wavefronts and a CU's whole 160 KiB of LDS (9), on 32x16-pixel tiles with the whole LDS (10),
-   11 = the shape of 8 on 16x32-pixel tiles (smaller brick rectangles where the view's shear runs along the image's x direction).
+   8 / 9 = the LDS-staged kernel with one apron copy per major axis (so that every tile marches through layers of its
+   own major axis with unit-stride DMA pieces) and the layer thickness chosen per tile: whole brick layers where they fit the tile's
+   LDS ring, half layers (two voxels, 80-byte slots) where they do not -- 8 on 32x16-pixel tiles, 9 on 16x32-pixel tiles whose ring
+   can also hold, per brick row, that row's own range (tiles whose bounding rectangles fit no other way: views near a body
+   diagonal).  16-bit volumes; on 8-bit ones 8 runs as 6 and 9 as 6 on 16x32-pixel tiles.  (10 / 11, the whole-LDS shapes round 4
+   measured and did not keep, are refused.)
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): under kernel variant 0 the launch is a MEASURED choice -- every candidate kernel of a configuration
@@ -176,7 +177,7 @@ int vr_set_kernel_variant(vr_handle h, int variant);
 int vr_set_autotune(vr_handle h, int enable);
 /* what the last launch ran as (for tests and tools; no reference equivalent): bit 0 relay kernel, bit 1 pipelined batch loop,
    bit 2 four-sample batches, bits 3..6 the LDS-staged trilinear kernel's shape (0 = not that kernel; the numbers of
-   vr_set_kernel_variant 6 .. 11 minus 5) */
+   vr_set_kernel_variant 6 .. 9 minus 5) */
 int vr_get_launch_choice(vr_handle h);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment (needs a stats build of vr_tslab.hip: make TSLAB_TAG=_st TSLAB_DEFS="-DVR_EXPERIMENTS -DVR_X_STATS", then
 VR_CORE_LIB=.../libvr_core_st.so): per-tile load-plan statistics of the LDS-staged TRILINEAR kernel on the bench workload.
-  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale] [kernel variant: 6, 8, 9, 10]"""
+  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale] [kernel variant: 6, 8, 9]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -21,7 +21,7 @@ if pose == "offaxis":
 elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
     r.cameraOrient(0.0, *[float(v) for v in pose.split(",")])
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 6
-TH, TWP = (32, 32) if variant == 9 else ((32, 16) if variant == 11 else (16, 32))              # rows per tile
+TH, TWP = (32, 16) if variant == 9 else (16, 32)              # rows per tile
 r.setKernelVariant(variant)
 r.render()
 print("kernel", r.last_kernel_name)

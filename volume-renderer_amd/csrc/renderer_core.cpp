@@ -48,7 +48,6 @@ RendererCore::~RendererCore()
         if (d_fb_) (void)hipFree(d_fb_);
         if (d_tf_) (void)hipFree(d_tf_);
         if (d_tile_table_) (void)hipFree(d_tile_table_);
-        if (d_tile_table32_) (void)hipFree(d_tile_table32_);
         if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
@@ -623,8 +622,8 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    // kernel variants 6 .. 11: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
-    L.tri_slab = (force_generic >= 6 && force_generic <= 11) ? force_generic - 5 : 0;
+    // kernel variants 6 .. 9: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
+    L.tri_slab = (force_generic >= 6 && force_generic <= 9) ? force_generic - 5 : 0;
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -773,11 +772,9 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         if (tri_path_candidate(P, L)) add(0);
         if (L.apron_y != nullptr && L.apron_x != nullptr) {
             add(3 << 3);
-            if (L.tile_table32 != nullptr) add(4 << 3);
-            add(5 << 3);
-            if (L.tile_table_tall != nullptr) add(6 << 3);
+            if (L.tile_table_tall != nullptr) add(4 << 3);
         } else if (L.bytes_per_voxel == 1 && L.tile_table_tall != nullptr && viewAxisAlignment(P) < 0.92) {
-            add(6 << 3);                                                 // 8-bit volumes, oblique views: whole layers on 16x32-pixel tiles
+            add(4 << 3);                                                 // 8-bit volumes, oblique views: whole layers on 16x32-pixel tiles
         }
     }
     if (n < 2) return;
@@ -938,9 +935,9 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     last_apron_bytes_ = apron_bytes_;
     // Half layers of the staged kernel (vr_tslab.hip, 16-bit volumes): two more copies with the bricks' planes along y / x
     // slowest, so that half a brick along any major axis is 80 contiguous bytes.  Built the first time a view is oblique
-    // to the volume axes (or kernel variants 8 .. 11 ask for them); +2 x 1.25 volumes of HBM.
+    // to the volume axes (or kernel variants 8 / 9 ask for them); +2 x 1.25 volumes of HBM.
     const bool oblique = viewAxisAlignment(P) < 0.92;
-    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 11) || (force_generic == 0 && oblique));
+    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 9) || (force_generic == 0 && oblique));
     if (want_perm && !apron_perm_failed_) {
         for (int o = 0; o < 2 && !apron_perm_failed_; o++) {
             if (d_apron_perm_[o]) continue;
@@ -1034,8 +1031,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
 {
     L.tile_table = nullptr;
     L.tile_table_blocks = 0;
-    L.tile_table32 = L.tile_table_tall = nullptr;
-    L.tile_table32_blocks = L.tile_table_tall_blocks = 0;
+    L.tile_table_tall = nullptr;
+    L.tile_table_tall_blocks = 0;
     if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
@@ -1046,8 +1043,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     const uint64_t shape_key = tileScheduleKey(P, rows, false);
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
-    const bool need32 = filter == 1 && tri_slab_candidate(P, L);   // 32x32- and 16x32-pixel tiles for the staged trilinear kernel's other shapes
-    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table32_blocks_ == 0)) {
+    const bool need32 = filter == 1 && tri_slab_candidate(P, L);   // 16x32-pixel tiles for the staged trilinear kernel's tall shape
+    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
         // synchronous copies: the tables are pageable temporaries
@@ -1062,11 +1059,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
             blocks = t.size();
         };
         upload(d_tile_table_, tile_table_capacity_, tile_table_blocks_, table);
-        tile_table32_blocks_ = tile_table_tall_blocks_ = 0;
+        tile_table_tall_blocks_ = 0;
         if (need32) {
-            std::vector<uint32_t> t32;
-            (void)buildTileSchedule(P, rows, t32, nullptr, 32u);
-            upload(d_tile_table32_, tile_table32_capacity_, tile_table32_blocks_, t32);
             std::vector<uint32_t> tall;
             (void)buildTileSchedule(P, rows, tall, nullptr, 32u, 16u);
             upload(d_tile_table_tall_, tile_table_tall_capacity_, tile_table_tall_blocks_, tall);
@@ -1076,7 +1070,6 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     }
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
-    if (need32 && tile_table32_blocks_ > 0) { L.tile_table32 = d_tile_table32_; L.tile_table32_blocks = (uint32_t)tile_table32_blocks_; }
     if (need32 && tile_table_tall_blocks_ > 0) { L.tile_table_tall = d_tile_table_tall_; L.tile_table_tall_blocks = (uint32_t)tile_table_tall_blocks_; }
     // Kernel choice per launch (all bit-identical; measured on cfg3 after the checked-head fix, tools/pose_sweep.py and
     // tools/shard_ms.py; `aligned` = central ray within ~23 degrees of a volume axis):
@@ -1099,7 +1092,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
         } else {
             double r1, r2;
             viewAxisRatios(P, r1, r2);
-            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 6 : 3;
+            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 4 : 3;
         }
     }
     // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is

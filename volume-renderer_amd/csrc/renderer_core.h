@@ -173,9 +173,7 @@ private:
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
-    uint32_t *d_tile_table32_ = nullptr;     // the same for 32x32-pixel tiles (vr_tslab.hip: 16-wavefront workgroups; 16-bit volumes); built with the table above
-    size_t tile_table32_capacity_ = 0, tile_table32_blocks_ = 0;
-    uint32_t *d_tile_table_tall_ = nullptr;  // ... and for 16x32-pixel tiles (8 wavefronts, two wide)
+    uint32_t *d_tile_table_tall_ = nullptr;  // the same for 16x32-pixel tiles (the staged trilinear kernel's tall shape); built with the table above
     size_t tile_table_tall_capacity_ = 0, tile_table_tall_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
@@ -187,7 +185,7 @@ private:
     // the first frames of a configuration double as measurements -- each candidate is timed a few times (HIP events on
     // the launch stream, polled without blocking), the fastest is kept until the configuration changes.
     // A candidate = bit set: 1 relay kernel, 2 pipelined batch loop, 4 four-sample batches; bits 3 .. 6: LaunchConfig::tri_slab
-    // (0 = batched trilinear kernel, 1 / 3 / 4 / 5 = the LDS-staged kernel in one of its shapes).
+    // (0 = batched trilinear kernel, 1 / 3 / 4 = the LDS-staged kernel in one of its shapes).
     // An entry settles on the fastest candidate after kTuneTries measurements of each (in an order shuffled per entry, so no
     // candidate is always the one measured on cold clocks), is measured ONCE more kTuneRevalidateFrames frames later (the first
     // ~25 frames after idle run ~15 % slow while the clocks ramp) and is evicted least-recently-used first.

@@ -81,8 +81,6 @@ struct LaunchConfig {
     int sparse_shard;              // use the 4-wavefront relay kernel when the shape allows
     const uint32_t *tile_table;    // device: work-ordered block -> tile table (nullptr = arithmetic order)
     uint32_t tile_table_blocks;
-    const uint32_t *tile_table32;  // device: the same for 32x32-pixel tiles (the staged trilinear kernel's 16-wavefront workgroups; nullptr = none)
-    uint32_t tile_table32_blocks;
     const uint32_t *tile_table_tall;   // device: the same for 16x32-pixel tiles (8 wavefronts, 2 x 4: the staged trilinear kernel's tall shape; nullptr = none)
     uint32_t tile_table_tall_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
@@ -90,7 +88,7 @@ struct LaunchConfig {
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     const void *apron_y, *apron_x; // device: the apron copy with the bricks' planes along y / x slowest (orders 1 and 2 of relayout_apron_kernel; nullptr = none): half layers of the staged kernel
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16 tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 16-bit volumes: 3 / 4 / 5 = per-axis copies and the layer thickness per tile, on 32x16 tiles / 32x32 tiles with 16 wavefronts and a CU's whole LDS / 32x16 tiles with the whole LDS (variants 8 / 9 / 10); 6 = shape 3 on 16x32-pixel tiles (variant 11)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16-pixel tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 3 = 16-bit volumes: per-axis copies and the layer thickness per tile (variant 8); 4 = 16x32-pixel tiles with rows (variant 9; 16-bit volumes as 3, 8-bit ones with whole layers)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

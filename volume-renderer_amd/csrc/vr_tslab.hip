@@ -55,19 +55,14 @@
 
 namespace vr {
 
-// Workgroup shapes (template parameters NW = wavefronts, LDSKB = KiB of LDS the workgroup declares):
-//   NW = 8,  LDSKB = 80:  one 32x16-pixel tile, two workgroups per CU.  The ring holds three 144-slot layers of 160 B for the
-//                         1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables take
-//                         20 KiB.  Three workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose
-//                         layers fit (512^3: 0.711 vs 0.713 ms): the loop is bound by VALU issue, not by latency -- but ONE
-//                         workgroup per CU (8 wavefronts) is 1.5x slower (1.25 -> 1.86 ms): two wavefronts per SIMD do not
-//                         cover each other's LDS latencies.
-//   NW = 16, LDSKB = 160: a 32x32-pixel tile (1024 threads) on a CU's whole LDS (gfx950: 160 KiB per workgroup): 16 wavefronts
-//                         per CU, 660 half-brick slots per layer three deep; footprints are larger and a frame is three rounds
-//                         of long tiles (+ 10 % at the default pose), but the few poses whose 32x16 tiles do not fit 80 KiB
-//                         even in half layers do fit here.
-//   NW = 8,  LDSKB = 160: the 32x16 tile with the whole LDS: everything fits, at 8 wavefronts per CU (views along a body
-//                         diagonal of the volume: 2.47 ms against 2.7-2.9 for the other two).
+// Workgroup shapes (template parameters NW = wavefronts, LDSKB = KiB of LDS the workgroup declares, TW = wavefronts per tile row):
+//   NW = 8, LDSKB = 80 is what ships: one 32x16- or 16x32-pixel tile per workgroup, two workgroups per CU.  The ring holds three
+//   144-slot layers of 160 B for the 1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables
+//   take 20 KiB.  Three workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose layers fit (512^3: 0.711
+//   vs 0.713 ms) -- but ONE workgroup per CU (8 wavefronts on the whole 160 KiB) is 1.5x slower (1.25 -> 1.86 ms): two wavefronts
+//   per SIMD do not cover each other's LDS round trips.  16 wavefronts on a 32x32-pixel tile and the whole LDS: + 10 % at the
+//   default pose, and a frame is three rounds of long tiles.  Both whole-LDS shapes were measured with whole and half layers
+//   (round 4) and are not instantiated any more; the parameters stay.
 constexpr float TS_MARGIN = 0.0625f;                      // voxels, on top of the drift bound
 constexpr int TS_FB_BATCH = 4;                            // samples whose taps a tile that is not staged requests together (six or eight: no faster)
 constexpr float TS_MIN_AXIS = 0.3f;                       // |G_m| >= this * |G|_inf at all four corners, else not staged
@@ -992,13 +987,14 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
 }
 
 // ------------------------------------------------------------------ dispatch
-// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0: u8; 1 .. 5: u16 (below); 6: u8 on 16x32-pixel tiles
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4: u8; 1 .. 3: u16 (below)
 template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
 {
-    const uint32_t *table = NW == 16 ? L.tile_table32 : (TW == 2 ? L.tile_table_tall : L.tile_table);
-    const uint32_t blocks = NW == 16 ? L.tile_table32_blocks : (TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks);
+    static_assert(NW == 8, "tile tables exist for 8-wavefront tiles");
+    const uint32_t *table = TW == 2 ? L.tile_table_tall : L.tile_table;
+    const uint32_t blocks = TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks;
     int no_stage = L.tri_slab == 2 ? 1 : 0;
     VR_TSLAB_CHK(if (std::getenv("VR_TSLAB_SABOTAGE") != nullptr) no_stage = 3;)   // checked build only: the plan guard's negative control
     hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM, TW>), dim3(blocks), dim3(64 * NW), 0, st, P,
@@ -1037,19 +1033,17 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
 }
 
 #define VR_TSLAB_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, hipStream_t st
-// 16-bit volumes, by workgroup shape (LaunchConfig::tri_slab; vr_set_kernel_variant 6 .. 10):
-//   tri_slab 1 (2 = staging off): 32x16 tiles, 80 KiB, order-0 copy, whole layers
-//   tri_slab 3: the same with the per-axis copies, layer thickness per tile (half layers where whole ones do not fit)
-//   tri_slab 4: 32x32 tiles, 16 wavefronts, a CU's whole LDS, per-axis copies, thickness per tile
-//   tri_slab 5: 32x16 tiles on a CU's whole LDS, per-axis copies, thickness per tile
-//   tri_slab 6: tri_slab 3 on 16x32-pixel tiles (two wavefronts wide, four tall)
-// (round 4 also measured the whole-LDS shapes with whole layers only: 32x16 tiles 1.96-2.13 ms over the orbit poses, 32x32
-// tiles 1.64-3.6 ms -- behind the half-layer shapes at every pose, not kept)
+// By workgroup shape (LaunchConfig::tri_slab; vr_set_kernel_variant 6 .. 9):
+//   tri_slab 1 (2 = staging off): 32x16-pixel tiles, 80 KiB, order-0 copy, whole layers (8- and 16-bit volumes)
+//   tri_slab 3: 16-bit volumes, the same tiles with the per-axis copies, layer thickness per tile (half layers where whole ones do not fit)
+//   tri_slab 4: 16x32-pixel tiles (two wavefronts wide, four tall), rows for the tiles that fit no other way; 16-bit volumes with
+//               the per-axis copies and the thickness per tile, 8-bit ones with whole layers
+// (round 4 also measured, and did not keep: whole layers only on a CU's whole LDS -- 32x16 tiles 1.96-2.13 ms over the orbit poses,
+// 32x32 tiles with 16 wavefronts 1.64-3.6 --; half layers on 32x32 tiles / 160 KiB 1.63-1.89, off-axis 2.73; half layers on 32x16 tiles
+// with the whole LDS 1.90-2.06, off-axis 2.39: behind the two shapes above at every pose once the 16x32 tiles had rows)
 hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS);
-hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS);
-hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS);
-hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);          // 8-bit volumes: whole layers on 16x32-pixel tiles (tri_slab 6)
+hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);
 
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
@@ -1057,21 +1051,16 @@ hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);          // 8-bit volumes: whole
 #if VR_TSLAB_TU == 0 || VR_TSLAB_TU == -1
 hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS)
 {
-    if (L.tri_slab == 6 && L.tile_table_tall != nullptr) return launch_tslab_u8_tall(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 4 && L.tile_table_tall != nullptr) return launch_tslab_u8_tall(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
-#endif
-#if VR_TSLAB_TU == 6 || VR_TSLAB_TU == -1
-hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false, 2>(P, L, vol, tf, fb, spp, st); }
 #endif
 #if VR_TSLAB_TU == 1 || VR_TSLAB_TU == -1
 hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
 {
-    const bool perm_ok = L.apron_y != nullptr && L.apron_x != nullptr, t32 = L.tile_table32 != nullptr;
+    const bool perm_ok = L.apron_y != nullptr && L.apron_x != nullptr;
     if (L.tri_slab == 3 && perm_ok) return launch_tslab_u16_half(P, L, vol, tf, fb, spp, st);
-    if (L.tri_slab == 4 && perm_ok && t32) return launch_tslab_u16_half16(P, L, vol, tf, fb, spp, st);
-    if (L.tri_slab == 5 && perm_ok) return launch_tslab_u16_halfwide(P, L, vol, tf, fb, spp, st);
-    if (L.tri_slab == 6 && perm_ok && L.tile_table_tall != nullptr) return launch_tslab_u16_halftall(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 4 && perm_ok && L.tile_table_tall != nullptr) return launch_tslab_u16_halftall(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint16_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -1079,13 +1068,10 @@ hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
 hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 80, true>(P, L, vol, tf, fb, spp, st); }
 #endif
 #if VR_TSLAB_TU == 3 || VR_TSLAB_TU == -1
-hipError_t launch_tslab_u16_half16(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 16, 160, true>(P, L, vol, tf, fb, spp, st); }
+hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 80, true, 2>(P, L, vol, tf, fb, spp, st); }
 #endif
 #if VR_TSLAB_TU == 4 || VR_TSLAB_TU == -1
-hipError_t launch_tslab_u16_halfwide(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 160, true>(P, L, vol, tf, fb, spp, st); }
-#endif
-#if VR_TSLAB_TU == 5 || VR_TSLAB_TU == -1
-hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 80, true, 2>(P, L, vol, tf, fb, spp, st); }
+hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false, 2>(P, L, vol, tf, fb, spp, st); }
 #endif
 
 }  // namespace vr
