@@ -215,9 +215,9 @@ def test_tri_slab_full_size_cfg3(vra, oracle):
                 frames[name] = r.readPixels().copy()
                 counts[name] = r.countSamples()
             print(f"cfg3 trilinear {pose}: " + ", ".join(f"{k} {kernels[k]} {ms[k]:.3f} ms" for k in ms))
-            assert kernels == {"staged": TSLAB, "half": TSLAB, "half16": TSLAB, "halfwide": TSLAB, "halftall": TSLAB, "batched": "raymarch_tri_kernel", "generic": "raymarch_generic_kernel"}
-            assert counts["staged"] == counts["half"] == counts["half16"] == counts["halfwide"] == counts["halftall"] == counts["batched"] == counts["generic"]
-            for k in ("staged", "half", "half16", "halfwide", "halftall"):
+            assert kernels == {"staged": TSLAB, "half": TSLAB, "halftall": TSLAB, "batched": "raymarch_tri_kernel", "generic": "raymarch_generic_kernel"}
+            assert counts["staged"] == counts["half"] == counts["halftall"] == counts["batched"] == counts["generic"]
+            for k in ("staged", "half", "halftall"):
                 assert np.array_equal(bits(frames[k]), bits(frames["generic"])), (pose, k)
             assert np.array_equal(bits(frames["batched"]), bits(frames["generic"])), pose
         # sparse rows against the oracle (default pose)

@@ -767,9 +767,6 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         prepare(std::true_type{}); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
         const bool ahead_ok = LA >= 2;
-        const bool clamp_tile = uniform_i(red[5]) != 0;
-        // voxels a step can advance along any axis (box units -> voxels: at most step * largest dimension / smallest extent)
-        const int clamp_L = 2 + (int)(P.step * nmax / fminf(fminf(P.ext[0], P.ext[1]), P.ext[2])) / T;
         float takenf = 0.0f;
         const float limitf = (float)rem;
         for (int p = 0; p < n_phases; p++) {
@@ -786,21 +783,25 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // shader's test before every sample, VolumeRenderer.cs:118; dest.a never decreases).
             // (a second, select-free copy of the body for the iterations in which every lane has a sample -- four out of five --
             // measured SLOWER: 1.65 vs 1.51 ms; the look-ups issued at the end of one copy are consumed by either)
-            // (round 4, ISA inspection: entering and leaving the sample loop costs 29 v_mov per phase -- the register allocator
-            // keeps the 14 loop-carried values in other registers outside it.  Two restructurings that avoid those were built
-            // and measured SLOWER, because the copies then moved INTO the sample loop: one loop per clamped / unclamped stretch
-            // of phases with a single copy of the body (1.25 -> 1.30 ms), and phases + samples as one flat loop with the end of
-            // a phase as a wave-uniform branch (1.34 ms; there the compiler also waits for taps and look-ups together))
+            // (round 4, ISA inspection: with the sample loop written `for (;;) { if (!any(here)) break; ... }` and two instances of
+            // it per phase (with / without the low-face clamp) the register allocator kept the 22 loop-carried values in other
+            // registers outside the loops: three sets of 22 v_mov per phase, ~150 issue cycles against ~860 for the phase's 4.3
+            // iterations.  One loop per clamped / unclamped stretch of phases (1.25 -> 1.30 ms) and phases + samples as one flat
+            // loop (1.34 ms) moved the copies INTO the sample loop.  What removes them: ONE instance of the loop, rotated by hand
+            // -- the continuation test at the bottom, `if (any) do { ... } while (any)` -- so that the values leave the loop in
+            // the registers the body wrote them to: no copies at all, 306 -> 178 VALU in the phase loop's text, 1.26 -> 1.17 ms.
+            // The single instance always clamps (three v_max, 13 cycles per iteration: less than the copies cost).
+            // Not available on this chip: d16 LDS loads into registers whose high halves hold 0x4B00 (the register would BE
+            // the float 2^23 + v, no conversion): with SRAM ECC the hardware zeroes the unused half (tools/ubench/d16_preserve.hip))
             auto phase_samples = [&](auto clamp_tag) {
-                for (;;) {
+                bool alive = takenf < limitf && da < 0.95f;
+                bool here = alive && lay == L;
+                if (__any(here ? 1 : 0)) do {
                     // RZ = 4: the layer BEHIND the two this phase reads is resident as well (requested two phases ago, landed before
                     // the last barrier), so a ray may run one layer ahead of the phase: lanes whose own layer has 4 samples fill the
                     // idle slot of the iteration that the 5-sample lanes need, and own a sample less in the next phase -- the
                     // wavefront then takes ~4.1 iterations per layer instead of max(4, 5) = 5.  The phase still ends when no lane is
                     // left IN layer L.
-                    const bool alive = takenf < limitf && da < 0.95f;
-                    const bool here = alive && lay == L;
-                    if (!__any(here ? 1 : 0)) break;
                     const bool valid = here || (alive && lay == Lnext && ahead_ok);
                     VR_TSLAB_STAT(st_iters++; st_samples += valid ? 1 : 0;)
                     VR_TSLAB_CHK(if (valid) chk_violations += check_taps(L);)
@@ -850,12 +851,11 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                         da += a * om;
                     }
                     weights();                                               // of the sample just prepared
-                }
+                    alive = takenf < limitf && da < 0.95f;
+                    here = alive && lay == L;
+                } while (__any(here ? 1 : 0));
             };
-            // (L <= clamp_L: with a ray running one layer ahead the sample prepared next may lie two layers on, and a step's
-            // worth of voxels beyond that)
-            if (clamp_tile || L <= clamp_L) phase_samples(std::true_type{});
-            else phase_samples(std::false_type{});
+            phase_samples(std::true_type{});
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
             slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
