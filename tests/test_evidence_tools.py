@@ -58,15 +58,26 @@ def test_traffic_is_attributed_to_the_kernel_the_bench_line_names(sandbox):
     e = json.loads((ROOT / "profiles" / "traffic.json").read_text())["unit_test_key"]
     assert e["kernel"] == "raymarch_fast_kernel" and e["instance"] == FAST_A and e["launches"] == 135
     assert e["bytes"] == int(2 * 1000.0 * 1024 + 10.0 * 1024)
-    # a run in which the named family never settles (a third of the launches) gives no figure at all
+    # the JSON line names the LAST launch's kernel: when that family never settles (a third of the launches) the figure belongs to
+    # the instance with more than half of the launches and says so (bench.py then refuses it for a line that names another kernel)
     out2 = sandbox / "prof2"
     out2.mkdir()
     (out2 / "a.log").write_text('{"config": {"kernel": "raymarch_relay_kernel"}}\n')
     write_pass(out2, "FETCH_SIZE", [(FAST_A, 135, 1000.0), (RELAY, 6, 2000.0)])
     write_pass(out2, "WRITE_SIZE", [(FAST_A, 135, 10.0), (RELAY, 6, 10.0)])
     p = run("pmc_traffic.py", out2, "unit_test_key2", profiles=sandbox)
+    assert p.returncode == 0, p.stderr
+    e = json.loads((ROOT / "profiles" / "traffic.json").read_text())["unit_test_key2"]
+    assert e["kernel"] == "raymarch_fast_kernel" and e["instance"] == FAST_A and e["bytes"] == int(2 * 1000.0 * 1024 + 10.0 * 1024)
+    # ... and a run without a settled kernel at all gives no figure
+    out4 = sandbox / "prof4"
+    out4.mkdir()
+    (out4 / "a.log").write_text('{"config": {"kernel": "raymarch_relay_kernel"}}\n')
+    write_pass(out4, "FETCH_SIZE", [(FAST_A, 60, 1000.0), (FAST_B, 60, 1000.0), (RELAY, 20, 2000.0)])
+    write_pass(out4, "WRITE_SIZE", [(FAST_A, 60, 10.0), (FAST_B, 60, 10.0), (RELAY, 20, 10.0)])
+    p = run("pmc_traffic.py", out4, "unit_test_key4", profiles=sandbox)
     assert p.returncode != 0 and "not the settled kernel" in (p.stderr + p.stdout)
-    assert "unit_test_key2" not in json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    assert "unit_test_key4" not in json.loads((ROOT / "profiles" / "traffic.json").read_text())
     # the bench line's alias for the staged trilinear kernel
     out3 = sandbox / "prof3"
     out3.mkdir()

@@ -57,28 +57,46 @@ def per_kernel(out, counter):
     return acc
 
 
+REV = {v: k for k, v in ALIAS.items()}
+
+
+def settled(acc, family, key, counter):
+    """(family, instance name, its values, ray-march launches of the run) of the settled kernel of one PMC pass: the most-launched
+    instance of `family` when it has at least a third of the run's ray-march launches; otherwise -- the JSON line names the LAST
+    launch's kernel, which under the profiler can be one of the work model's re-measurements -- the instance with more than half
+    of the launches, whatever its family; otherwise none (exit)"""
+    symbol = ALIAS.get(family, family)
+    march = {k: v for k, v in acc.items() if "raymarch_" in k}
+    total = sum(len(v) for v in march.values())
+    mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
+    name = max(mine, key=lambda k: len(mine[k])) if mine else None
+    if name is not None and 3 * len(mine[name]) >= total:
+        return family, name, mine[name], total
+    top = max(march, key=lambda k: len(march[k])) if march else None
+    if top is not None and 2 * len(march[top]) > total:
+        sym = re.search(r"(raymarch_\w+)", top).group(1)
+        return REV.get(sym, sym), top, march[top], total
+    if name is None:
+        sys.exit(f"{key}: no launches of {symbol} in the {counter} pass ({sorted(march)})")
+    sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass -- not the settled kernel")
+
+
 def main():
     out, key = sys.argv[1], sys.argv[2]
-    family = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
-    if not family:
+    named = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
+    if not named:
         sys.exit(f"{key}: no kernel family given and no bench JSON line in {out}/*.log")
-    symbol = ALIAS.get(family, family)
-    vals, picked, instances = {}, None, []
+    vals, picked, instances, family = {}, None, [], named
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        acc = per_kernel(out, counter)
-        march = {k: v for k, v in acc.items() if "raymarch_" in k}
-        total = sum(len(v) for v in march.values())
-        mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
-        if not mine:
-            sys.exit(f"{key}: no launches of {symbol} in the {counter} pass ({sorted(march)})")
-        name = max(mine, key=lambda k: len(mine[k]))
-        if 3 * len(mine[name]) < total:
-            sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass -- not the settled kernel")
+        fam, name, v, total = settled(per_kernel(out, counter), named, key, counter)
+        if picked is not None and fam != family:
+            sys.exit(f"{key}: the passes settled on different kernel families ({family}, {fam})")
+        family = fam
         # (two passes may settle on different instances of one family when two candidates tie -- the fast kernel's plain and
         # pipelined loops on a full frame: both are recorded)
         instances.append(name)
         picked = name if picked is None else picked
-        vals[counter] = (sum(mine[name]) / len(mine[name]), len(mine[name]), total)
+        vals[counter] = (sum(v) / len(v), len(v), total)
     traffic = int(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024)
     root = Path(__file__).resolve().parent.parent
     dst = root / "profiles" / "traffic.json"

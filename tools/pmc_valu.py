@@ -9,36 +9,29 @@ output directory -> profiles/valu.json (bench.py: `roofline_valu`).
                         loops and the measured per-instruction costs (tools/valu_cpi.py -> profiles/valu_cpi.json)
 
 Kernel selection as in tools/pmc_traffic.py: grouped by the full kernel name, the family the run's own JSON line names, the
-most-launched instance, at least a third of the run's ray-march launches.
+most-launched instance, at least a third of the run's ray-march launches (else the instance with more than half of them).
 usage: tools/pmc_valu.py <profile output dir> <key> [kernel family]"""
 import json
-import re
 import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
-from pmc_traffic import ALIAS, kernel_from_logs, per_kernel
+from pmc_traffic import kernel_from_logs, per_kernel, settled
 
 
 def main():
     out, key = sys.argv[1], sys.argv[2]
-    family = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
-    if not family:
+    named = sys.argv[3] if len(sys.argv) > 3 else kernel_from_logs(out)
+    if not named:
         sys.exit(f"{key}: no kernel family given and no bench JSON line in {out}/*.log")
-    symbol = ALIAS.get(family, family)
-    vals, picked = {}, None
+    vals, picked, family = {}, None, named
     for counter in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"):
-        acc = per_kernel(out, counter)
-        march = {k: v for k, v in acc.items() if "raymarch_" in k}
-        total = sum(len(v) for v in march.values())
-        mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
-        if not mine:
-            sys.exit(f"{key}: no launches of {symbol} in the {counter} pass")
-        name = max(mine, key=lambda k: len(mine[k]))
-        if 3 * len(mine[name]) < total:
-            sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass")
+        fam, name, v, _ = settled(per_kernel(out, counter), named, key, counter)
+        if picked is not None and fam != family:
+            sys.exit(f"{key}: the passes settled on different kernel families ({family}, {fam})")
+        family = fam
         picked = name if picked is None else picked
-        vals[counter] = (sum(mine[name]) / len(mine[name]), len(mine[name]))
+        vals[counter] = (sum(v) / len(v), len(v))
     root = Path(__file__).resolve().parent.parent
     dst = root / "profiles" / "valu.json"
     d = json.loads(dst.read_text()) if dst.exists() else {}

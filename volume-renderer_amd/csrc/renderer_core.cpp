@@ -706,6 +706,11 @@ void RendererCore::launch(uint32_t *spp)
     tune_measure_ = false;
 }
 
+// TRILINEAR on 16-bit volumes: whole brick layers are the first guess -- and the per-axis copies are not built -- only while the
+// central ray keeps this share of its length along one volume axis: at 0.973 (a fifth of a voxel of shear per voxel) the
+// per-tile layer thickness already wins, 1.33 against 1.46 ms on cfg3; at 1.0 whole layers do, 1.17 against 1.20
+static constexpr double kTriWholeLayerAlignment = 0.985;
+
 // ---- the measured work model.  Which kernel is fastest for a launch depends on how many tiles have work, how long
 // their rays are, how early they end and how oblique the view is (tools/config_sweep.py: the relay kernel wins a
 // 1024^3 shard with 171 active tiles by 25 %, loses a 256^3 frame with 560 by 45 %).  Round 2 chose by tile-count
@@ -936,7 +941,7 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     // Half layers of the staged kernel (vr_tslab.hip, 16-bit volumes): two more copies with the bricks' planes along y / x
     // slowest, so that half a brick along any major axis is 80 contiguous bytes.  Built the first time a view is oblique
     // to the volume axes (or kernel variants 8 / 9 ask for them); +2 x 1.25 volumes of HBM.
-    const bool oblique = viewAxisAlignment(P) < 0.92;
+    const bool oblique = viewAxisAlignment(P) < kTriWholeLayerAlignment;
     const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 9) || (force_generic == 0 && oblique));
     if (want_perm && !apron_perm_failed_) {
         for (int o = 0; o < 2 && !apron_perm_failed_; o++) {
@@ -1087,7 +1092,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // layers (round 4: orbit poses 1.43-1.62 ms against 2.9-3.4 whole-layer / 2.6-3.0 batched), on 16x32-pixel tiles with the
     // ring's rows holding their own brick ranges when the view runs near a body diagonal of the volume (1.68 ms against 3.0).
     if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L)) {
-        if (aligned || L.bytes_per_voxel == 1) {
+        if (viewAxisAlignment(P) >= kTriWholeLayerAlignment || L.bytes_per_voxel == 1) {
             L.tri_slab = 1;
         } else {
             double r1, r2;
