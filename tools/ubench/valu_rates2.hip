@@ -54,6 +54,12 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
         if (OP == 32) asm volatile(R16("v_add_f32 v10, 1.0, v2\n v_add_f32 v11, 0.5, v3\n v_add_f32 v12, -0.5, v2\n v_add_f32 v13, 2.0, v3\n v_add_f32 v14, 1.0, v2\n v_add_f32 v15, 0.5, v3\n v_add_f32 v16, -0.5, v2\n v_add_f32 v17, 2.0, v3\n") ::: CLOB);
         if (OP == 33) asm volatile(R16("v_add_f32 v10, s10, v2\n v_add_f32 v11, s11, v3\n v_add_f32 v12, s10, v2\n v_add_f32 v13, s11, v3\n v_add_f32 v14, s10, v2\n v_add_f32 v15, s11, v3\n v_add_f32 v16, s10, v2\n v_add_f32 v17, s11, v3\n") ::: CLOB);
         if (OP == 34) asm volatile(R16("v_fma_f32 v10, v2, s10, v3\n v_fma_f32 v11, v2, s11, v3\n v_fma_f32 v12, v2, s10, v3\n v_fma_f32 v13, v2, s11, v3\n v_fma_f32 v14, v2, s10, v3\n v_fma_f32 v15, v2, s11, v3\n v_fma_f32 v16, v2, s10, v3\n v_fma_f32 v17, v2, s11, v3\n") ::: CLOB);
+        if (OP == 35) asm volatile(R16("v_add_f32_e64 v10, v2, v3 clamp\n v_add_f32_e64 v11, v2, v3 clamp\n v_add_f32_e64 v12, v2, v3 clamp\n v_add_f32_e64 v13, v2, v3 clamp\n v_add_f32_e64 v14, v2, v3 clamp\n v_add_f32_e64 v15, v2, v3 clamp\n v_add_f32_e64 v16, v2, v3 clamp\n v_add_f32_e64 v17, v2, v3 clamp\n") ::: CLOB);
+        if (OP == 36) asm volatile(R16("v_add_f32_e64 v10, v2, v3\n v_add_f32_e64 v11, v2, v3\n v_add_f32_e64 v12, v2, v3\n v_add_f32_e64 v13, v2, v3\n v_add_f32_e64 v14, v2, v3\n v_add_f32_e64 v15, v2, v3\n v_add_f32_e64 v16, v2, v3\n v_add_f32_e64 v17, v2, v3\n") ::: CLOB);
+        if (OP == 37) asm volatile(R16("v_add_f32_e64 v10, v2, -0.5 clamp\n v_add_f32_e64 v11, v3, -0.5 clamp\n v_add_f32_e64 v12, v2, -0.5 clamp\n v_add_f32_e64 v13, v3, -0.5 clamp\n v_add_f32_e64 v14, v2, -0.5 clamp\n v_add_f32_e64 v15, v3, -0.5 clamp\n v_add_f32_e64 v16, v2, -0.5 clamp\n v_add_f32_e64 v17, v3, -0.5 clamp\n") ::: CLOB);
+        if (OP == 38) asm volatile(R16("v_mul_f32_e64 v10, v2, v3 clamp\n v_mul_f32_e64 v11, v2, v3 clamp\n v_mul_f32_e64 v12, v2, v3 clamp\n v_mul_f32_e64 v13, v2, v3 clamp\n v_mul_f32_e64 v14, v2, v3 clamp\n v_mul_f32_e64 v15, v2, v3 clamp\n v_mul_f32_e64 v16, v2, v3 clamp\n v_mul_f32_e64 v17, v2, v3 clamp\n") ::: CLOB);
+        if (OP == 39) asm volatile(R16("v_fma_f32 v10, v2, v3, v4 clamp\n v_fma_f32 v11, v2, v3, v4 clamp\n v_fma_f32 v12, v2, v3, v4 clamp\n v_fma_f32 v13, v2, v3, v4 clamp\n v_fma_f32 v14, v2, v3, v4 clamp\n v_fma_f32 v15, v2, v3, v4 clamp\n v_fma_f32 v16, v2, v3, v4 clamp\n v_fma_f32 v17, v2, v3, v4 clamp\n") ::: CLOB);
+        if (OP == 40) asm volatile(R16("v_add_f32_e64 v10, v2, v3 mul:2\n v_add_f32_e64 v11, v2, v3 mul:2\n v_add_f32_e64 v12, v2, v3 mul:2\n v_add_f32_e64 v13, v2, v3 mul:2\n v_add_f32_e64 v14, v2, v3 mul:2\n v_add_f32_e64 v15, v2, v3 mul:2\n v_add_f32_e64 v16, v2, v3 mul:2\n v_add_f32_e64 v17, v2, v3 mul:2\n") ::: CLOB);
         if (OP == 21) asm volatile(R16("s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n"
                                        "s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n") ::: CLOB);
     }
@@ -86,5 +92,7 @@ int main()
     run<21>("s_and_b64 / s_or_b64");
     run<22>("v_max_i32"); run<23>("v_min_u32"); run<24>("v_and_b32"); run<25>("v_lshlrev_b32"); run<26>("v_bfe_u32"); run<27>("v_mul_u32_u24"); run<28>("v_med3_f32"); run<29>("v_mul_f32"); run<30>("v_add3_u32"); run<31>("v_sub_f32");
     run<32>("v_add_f32 (inline constant src0)"); run<33>("v_add_f32 (sgpr src0)"); run<34>("v_fma_f32 (sgpr src1)");
+    // round 4: the VOP3 output modifiers (a clamp to [0, 1] on coordinates scaled by a power of two would replace v_max_f32(x, 0))
+    run<36>("v_add_f32_e64 (VOP3 encoding)"); run<35>("v_add_f32_e64 clamp"); run<37>("v_add_f32_e64 -0.5 clamp"); run<38>("v_mul_f32_e64 clamp"); run<39>("v_fma_f32 clamp"); run<40>("v_add_f32_e64 mul:2");
     return 0;
 }

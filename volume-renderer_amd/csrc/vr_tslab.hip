@@ -744,16 +744,18 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                 }
             return bad;
         };)
-        // CLAMP = false: the phase's samples are at least half a voxel away from the volume's low faces on every axis (the
-        // tile's corner rays say so for the minor axes, the layer index for the major one), so u = f - 0.5 >= 0 without
-        // the max (v_max_f32 issues at the slow rate: 3 x 4.4 of the loop's ~245 cycles)
-        auto prepare = [&](auto clamp_tag) {
-            constexpr bool CLAMP = decltype(clamp_tag)::value;
+        // The shader's u = max(f - 0.5, 0), i = floor(u), w = u - i WITHOUT the max (v_max_f32 issues at the slow rate, 4.5 cycles;
+        // three per sample): a sample the march takes lies in the box, f >= 0, so u' = f - 0.5 > -1 and the conversion's
+        // truncation already gives i = 0 where the max would; the weight is (u' - trunc(u')) with the subtraction's CLAMP
+        // modifier (output clamped to [0, 1], free: tools/ubench/valu_rates2.hip) -- u' itself below zero, i.e. 0, and
+        // u - floor(u) exactly (both are exact subtractions) everywhere else.  (A lane's position one step beyond its last
+        // sample may lie outside the box: its look-ups and taps read whatever LDS holds there -- out-of-range LDS reads
+        // return zero -- and are never composited.)
+        auto prepare = [&](auto) {
             float fx, fy, fz;
             scaled_here(fx, fy, fz);
-            if (CLAMP) { ux = fmaxf(fx - 0.5f, 0.0f); uy = fmaxf(fy - 0.5f, 0.0f); uz = fmaxf(fz - 0.5f, 0.0f); }
-            else { ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f; }
-            const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor: u >= 0
+            ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f;
+            const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor(max(u, 0)): truncation, u > -1
             VR_TSLAB_CHK(chk_idx[0] = i0; chk_idx[1] = j0; chk_idx[2] = k0;)
             lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> LSH;
             uint32_t p0, punused = 0, q0, q1, z0, z1;
@@ -763,7 +765,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             const uint32_t pz0 = p0 + z0, pz1 = p0 + z1;
             a00 = pz0 + q0; a10 = pz0 + q1; a01 = pz1 + q0; a11 = pz1 + q1;
         };
-        auto weights = [&]() { wx = __builtin_amdgcn_fractf(ux); wy = __builtin_amdgcn_fractf(uy); wz = __builtin_amdgcn_fractf(uz); };   // == u - floor(u), exact: u >= 0
+        auto sat_sub = [](float a, float b) { float r; asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; };
+        auto weights = [&]() { wx = sat_sub(ux, __builtin_truncf(ux)); wy = sat_sub(uy, __builtin_truncf(uy)); wz = sat_sub(uz, __builtin_truncf(uz)); };
         prepare(std::true_type{}); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
         const bool ahead_ok = LA >= 2;
