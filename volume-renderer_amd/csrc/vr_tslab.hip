@@ -248,6 +248,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // window + classification of one interpolated sample (VolumeRenderer.cs:122-131 / :164)
     auto classify = [&](float sv, float &c, float &cg, float &cb, float &a) {
         sv = __builtin_amdgcn_fmed3f(sv, k_fmin, k_fmax);                // == min(max(sv, fmin), fmax): fmin <= fmax, never NaN here; one instruction
+        // (the clamp moved behind the division as the last fma's clamp modifier -- below the window the quotient is negative, above
+        // it >= 1 -- is bit-exact too (20 000-trial campaign) and saves the v_med3, but measured no faster: 1.1465 vs 1.1428 ms)
         sv = div_cert(sv - k_fmin, k_fden, k_rden);
         if (MODE >= 2) {
             int idx = (int)(sv * tf_scale + 0.5f);                       // sv in [0, 1]: truncation == floor
