@@ -638,6 +638,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             rowtab[(L & 3) * 32 + (int)lane] = make_uint2(rowbase, (uint32_t)la_row | ((uint32_t)w << 8));
         }
     };
+    // (round 4, measured and not kept: the lanes' torus-relative positions and wrapped source offsets cached in registers and
+    // recomputed under a wave-uniform branch only when the rectangle's torus origin moves -- two compares per piece and layer
+    // instead of 13 VALU: SLOWER, 1.142 -> 1.153 ms at the default pose, 0.448 -> 0.465 on the cfg2 shape, orbit poses + 1-3 %.
+    // A phase's instructions outside the sample loop are not what its time follows)
     auto issue_layer = [&](int L) {
         if (L < Llo || L > Lhi) return;
         const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
