@@ -708,17 +708,26 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         // so a ray that waits for its layer's phase keeps the values across the barrier instead of recomputing them.
         uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0;
         float wx = 0.0f, wy = 0.0f, wz = 0.0f;
-        int lay = -0x7fffffff;
+        int lay = -0x7fffffff;                                            // of the prepared sample, + LAY_BIAS
+        const int LAY_BIAS = (int)(0x4B000000u >> (2 + LSH));
         // virtual table bases: real base - first index (unsigned wrap-around is fine, the sum is what is used)
         const uint32_t tab_a_b = lds_offset_of(tab_a) - 2u * (uint32_t)ia_lo, tab_b_b = lds_offset_of(tab_b) - 2u * (uint32_t)ib_lo, tab_m_b = lds_offset_of(tab_m) - 4u * (uint32_t)im_lo;
-        // byte offset of voxel index `idx` (and of idx + 1) along voxel axis AX, from the table of the role AX plays
-        auto look = [&](auto ax_tag, int idx, uint32_t &o0, uint32_t &o1) {
+        // byte offset of voxel index `t` (a non-negative whole number held as a float; and of t + 1) along voxel axis AX, from the
+        // table of the role AX plays.  No float -> int conversion and no shift (v_cvt_i32_f32 and v_lshl_add_u32 issue at the slow
+        // rate, 4.35 cycles each): 2^23 + 2 t (4 t for the 32-bit table) is exact, its BITS are 0x4B000000 + 2 t, and the table's
+        // virtual base minus 0x4B000000 sits in a vector register -- one fma and one integer add at the fast rate
+        const float k_magic = in_vgpr(8388608.0f);
+        uint32_t mb_a = tab_a_b - 0x4B000000u, mb_b = tab_b_b - 0x4B000000u, mb_m = tab_m_b - 0x4B000000u;
+        asm volatile("" : "+v"(mb_a), "+v"(mb_b), "+v"(mb_m));
+        auto look = [&](auto ax_tag, float t, uint32_t &o0, uint32_t &o1, uint32_t &bits) {
             constexpr int AX = decltype(ax_tag)::value;
             if (AX == M) {
-                VR_LDS_AS const uint32_t *e = reinterpret_cast<VR_LDS_AS const uint32_t *>((size_t)(tab_m_b + 4u * (uint32_t)idx));
+                bits = __float_as_uint(__builtin_fmaf(t, 4.0f, k_magic));
+                VR_LDS_AS const uint32_t *e = reinterpret_cast<VR_LDS_AS const uint32_t *>((size_t)(bits + mb_m));
                 o0 = e[0]; if (AX != PA) o1 = e[1];
             } else {
-                VR_LDS_AS const uint16_t *e = reinterpret_cast<VR_LDS_AS const uint16_t *>((size_t)((AX == A ? tab_a_b : tab_b_b) + 2u * (uint32_t)idx));
+                bits = __float_as_uint(__builtin_fmaf(t, 2.0f, k_magic));
+                VR_LDS_AS const uint16_t *e = reinterpret_cast<VR_LDS_AS const uint16_t *>((size_t)(bits + (AX == A ? mb_a : mb_b)));
                 o0 = e[0]; if (AX != PA) o1 = e[1];
             }
         };
@@ -757,22 +766,24 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         // u - floor(u) exactly (both are exact subtractions) everywhere else.  (A lane's position one step beyond its last
         // sample may lie outside the box: its look-ups and taps read whatever LDS holds there -- out-of-range LDS reads
         // return zero -- and are never composited.)
+        float tx = 0.0f, ty = 0.0f, tz = 0.0f;
         auto prepare = [&](auto) {
             float fx, fy, fz;
             scaled_here(fx, fy, fz);
             ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f;
-            const int i0 = (int)ux, j0 = (int)uy, k0 = (int)uz;          // == floor(max(u, 0)): truncation, u > -1
-            VR_TSLAB_CHK(chk_idx[0] = i0; chk_idx[1] = j0; chk_idx[2] = k0;)
-            lay = (M == 0 ? i0 : (M == 1 ? j0 : k0)) >> LSH;
-            uint32_t p0, punused = 0, q0, q1, z0, z1;
-            look(std::integral_constant<int, PA>{}, PA == 0 ? i0 : j0, p0, punused);   // the second taps of the pairs are the first ones' next elements (apron)
-            look(std::integral_constant<int, O1>{}, O1 == 0 ? i0 : j0, q0, q1);
-            look(std::integral_constant<int, O2>{}, k0, z0, z1);
+            tx = __builtin_truncf(ux); ty = __builtin_truncf(uy); tz = __builtin_truncf(uz);   // == floor(max(u, 0)) as a float: u > -1 (-0.0 counts as 0 below)
+            VR_TSLAB_CHK(chk_idx[0] = (int)tx; chk_idx[1] = (int)ty; chk_idx[2] = (int)tz;)
+            uint32_t p0, punused = 0, q0, q1, z0, z1, bp, bq, bz;
+            look(std::integral_constant<int, PA>{}, PA == 0 ? tx : ty, p0, punused, bp);   // the second taps of the pairs are the first ones' next elements (apron)
+            look(std::integral_constant<int, O1>{}, O1 == 0 ? tx : ty, q0, q1, bq);
+            look(std::integral_constant<int, O2>{}, tz, z0, z1, bz);
+            // the layer, biased: (0x4B000000 + 4 i) >> (2 + LSH) == LAY_BIAS + (i >> LSH)
+            lay = (int)((M == PA ? bp : (M == O1 ? bq : bz)) >> (2 + LSH));
             const uint32_t pz0 = p0 + z0, pz1 = p0 + z1;
             a00 = pz0 + q0; a10 = pz0 + q1; a01 = pz1 + q0; a11 = pz1 + q1;
         };
         auto sat_sub = [](float a, float b) { float r; asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; };
-        auto weights = [&]() { wx = sat_sub(ux, __builtin_truncf(ux)); wy = sat_sub(uy, __builtin_truncf(uy)); wz = sat_sub(uz, __builtin_truncf(uz)); };
+        auto weights = [&]() { wx = sat_sub(ux, tx); wy = sat_sub(uy, ty); wz = sat_sub(uz, tz); };
         prepare(std::true_type{}); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
         const bool ahead_ok = LA >= 2;
@@ -804,14 +815,14 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // the float 2^23 + v, no conversion): with SRAM ECC the hardware zeroes the unused half (tools/ubench/d16_preserve.hip))
             auto phase_samples = [&](auto clamp_tag) {
                 bool alive = takenf < limitf && da < 0.95f;
-                bool here = alive && lay == L;
+                bool here = alive && lay == L + LAY_BIAS;
                 if (__any(here ? 1 : 0)) do {
                     // RZ = 4: the layer BEHIND the two this phase reads is resident as well (requested two phases ago, landed before
                     // the last barrier), so a ray may run one layer ahead of the phase: lanes whose own layer has 4 samples fill the
                     // idle slot of the iteration that the 5-sample lanes need, and own a sample less in the next phase -- the
                     // wavefront then takes ~4.1 iterations per layer instead of max(4, 5) = 5.  The phase still ends when no lane is
                     // left IN layer L.
-                    const bool valid = here || (alive && lay == Lnext && ahead_ok);
+                    const bool valid = here || (alive && lay == Lnext + LAY_BIAS && ahead_ok);
                     VR_TSLAB_STAT(st_iters++; st_samples += valid ? 1 : 0;)
                     VR_TSLAB_CHK(if (valid) chk_violations += check_taps(L);)
                     const float vf = valid ? 1.0f : 0.0f;
@@ -861,7 +872,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     }
                     weights();                                               // of the sample just prepared
                     alive = takenf < limitf && da < 0.95f;
-                    here = alive && lay == L;
+                    here = alive && lay == L + LAY_BIAS;
                 } while (__any(here ? 1 : 0));
             };
             phase_samples(std::true_type{});
