@@ -60,6 +60,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
         if (OP == 38) asm volatile(R16("v_mul_f32_e64 v10, v2, v3 clamp\n v_mul_f32_e64 v11, v2, v3 clamp\n v_mul_f32_e64 v12, v2, v3 clamp\n v_mul_f32_e64 v13, v2, v3 clamp\n v_mul_f32_e64 v14, v2, v3 clamp\n v_mul_f32_e64 v15, v2, v3 clamp\n v_mul_f32_e64 v16, v2, v3 clamp\n v_mul_f32_e64 v17, v2, v3 clamp\n") ::: CLOB);
         if (OP == 39) asm volatile(R16("v_fma_f32 v10, v2, v3, v4 clamp\n v_fma_f32 v11, v2, v3, v4 clamp\n v_fma_f32 v12, v2, v3, v4 clamp\n v_fma_f32 v13, v2, v3, v4 clamp\n v_fma_f32 v14, v2, v3, v4 clamp\n v_fma_f32 v15, v2, v3, v4 clamp\n v_fma_f32 v16, v2, v3, v4 clamp\n v_fma_f32 v17, v2, v3, v4 clamp\n") ::: CLOB);
         if (OP == 40) asm volatile(R16("v_add_f32_e64 v10, v2, v3 mul:2\n v_add_f32_e64 v11, v2, v3 mul:2\n v_add_f32_e64 v12, v2, v3 mul:2\n v_add_f32_e64 v13, v2, v3 mul:2\n v_add_f32_e64 v14, v2, v3 mul:2\n v_add_f32_e64 v15, v2, v3 mul:2\n v_add_f32_e64 v16, v2, v3 mul:2\n v_add_f32_e64 v17, v2, v3 mul:2\n") ::: CLOB);
+        if (OP == 41) asm volatile(R16(OPS8_1("v_trunc_f32")) ::: CLOB);
+        if (OP == 42) asm volatile(R16("v_add_u32 v10, s10, v2\n v_add_u32 v11, s11, v3\n v_add_u32 v12, s10, v2\n v_add_u32 v13, s11, v3\n v_add_u32 v14, s10, v2\n v_add_u32 v15, s11, v3\n v_add_u32 v16, s10, v2\n v_add_u32 v17, s11, v3\n") ::: CLOB);
+        if (OP == 43) asm volatile(R16("v_fma_f32 v10, 2.0, v2, v3\n v_fma_f32 v11, 4.0, v2, v3\n v_fma_f32 v12, 2.0, v2, v3\n v_fma_f32 v13, 4.0, v2, v3\n v_fma_f32 v14, 2.0, v2, v3\n v_fma_f32 v15, 4.0, v2, v3\n v_fma_f32 v16, 2.0, v2, v3\n v_fma_f32 v17, 4.0, v2, v3\n") ::: CLOB);
         if (OP == 21) asm volatile(R16("s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n"
                                        "s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n s_and_b64 s[10:11], s[10:11], vcc\n s_or_b64 s[10:11], s[10:11], vcc\n") ::: CLOB);
     }
@@ -94,5 +97,6 @@ int main()
     run<32>("v_add_f32 (inline constant src0)"); run<33>("v_add_f32 (sgpr src0)"); run<34>("v_fma_f32 (sgpr src1)");
     // round 4: the VOP3 output modifiers (a clamp to [0, 1] on coordinates scaled by a power of two would replace v_max_f32(x, 0))
     run<36>("v_add_f32_e64 (VOP3 encoding)"); run<35>("v_add_f32_e64 clamp"); run<37>("v_add_f32_e64 -0.5 clamp"); run<38>("v_mul_f32_e64 clamp"); run<39>("v_fma_f32 clamp"); run<40>("v_add_f32_e64 mul:2");
+    run<41>("v_trunc_f32"); run<42>("v_add_u32 (sgpr src0)"); run<43>("v_fma_f32 (inline constant src0)");
     return 0;
 }
