@@ -12,7 +12,8 @@ Cost classes (cycles per wave-instruction per SIMD, sustained, six wavefronts pe
     2.8   v_fma_f32 / v_fmac_f32 / v_mac_f32
     4.3   everything else: v_max/min/med3, v_fract, every conversion, v_lshlrev, v_bfe, 24-bit multiplies, every
           three-operand integer op, v_cndmask, every v_cmp, cross-lane ops
-    4.2   an fp32 add / mul / fma of the first two classes with an SGPR operand
+    4.2   an instruction of the first two classes with an SGPR operand (fp32 and integer alike)
+Output modifiers (clamp, mul:2 ...) and inline constants cost nothing (profiles/r04_valu_rates2.txt).
 A hot loop = a loop at the kernel's deepest nesting level that contains the tap loads (LDS reads for the staged kernel,
 buffer / global loads for the others)."""
 import json
@@ -38,9 +39,10 @@ PROBES = {
 def cost(mnem, operands):
     base = mnem.replace("_e32", "").replace("_e64", "").replace("_sdwa", "").replace("_dpp", "")
     if base in FAST or base in FMA:
-        # an SGPR source on an fp32 add / mul / fma issues at the slow rate (inline constants do not)
+        # an SGPR source on a fast-rate instruction -- fp32 add / mul / fma and integer add alike (round 4: v_add_u32 with an SGPR
+        # operand 4.14 cycles) -- issues at the slow rate (inline constants do not)
         srcs = operands.split(",")[1:]
-        if base.endswith("_f32") and any(re.match(r"\s*-?\|?s(\d+|\[)", s) for s in srcs):
+        if any(re.match(r"\s*-?\|?s(\d+|\[)", s) for s in srcs):
             return 4.2, "sgpr"
         return (2.3, "fast") if base in FAST else (2.8, "fma")
     return 4.3, "slow"

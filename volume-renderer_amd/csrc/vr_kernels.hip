@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "vr_device.h"
+#include "vr_lds_dma.h"
 
 // Translation units: the ray-march kernels of one (voxel type, layout) pair are ~150 template
 // instances each, so the Makefile compiles this file five times in parallel:
@@ -371,6 +372,8 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         constexpr int LUT_SHIFT = 3;
         // byte offset of entry 0 relative to texel*entry_bytes (MODE 2: of index byte 0 relative to texel)
         const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
+        uint32_t lut_entry0 = lds_offset_of(lut) + (uint32_t)lut_bias;
+        asm volatile("" : "+v"(lut_entry0));
         // window + classification of one texel -> premultiplied colour c (cg, cb only in MODE 2)
         // and opacity a of VolumeRenderer.cs:130-131
         auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
@@ -382,9 +385,13 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
                     c = q.x; cg = q.y; cb = q.z; a = q.w;
                 } else {
-                    const char *entry = reinterpret_cast<const char *>(lut) + (uint32_t)((t << LUT_SHIFT) + lut_bias);
-                    const float2 ca = *reinterpret_cast<const float2 *>(entry);
-                    c = ca.x; a = ca.y;
+                    // one v_lshl_add_u32 with the table's LDS address + bias in a VECTOR register (the compiler's form was shift,
+                    // mask, add with an SGPR operand: two more slow-rate instructions per sample)
+                    uint32_t entry;
+                    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(entry) : "v"(t), "v"(lut_entry0));
+                    static_assert(LUT_SHIFT == 3, "the shift is spelled out in the instruction above");
+                    VR_LDS_AS const float *ca = reinterpret_cast<VR_LDS_AS const float *>((size_t)entry);      // (one ds_read_b64)
+                    c = ca[0]; a = ca[1];
                 }
             } else {
                 float s = (float)texel;
@@ -399,6 +406,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;
         const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
         const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+        // (in VECTOR registers for the sample loop: a VALU instruction with an SGPR operand issues at the slow rate on gfx950, 4.2
+        // cycles instead of 2.3 -- fp32 and integer alike, tools/ubench/valu_rates2.hip)
+        float Szv = Sz, Syv = Sy;
+        asm volatile("" : "+v"(Szv), "+v"(Syv));
         // ---- exact empty-space skipping (vr_set_skip_empty): a batch is skipped when the
         // dilated cell-max grid says every voxel within one 8^3 cell of the batch's middle
         // sample classifies to (0,0,0,0), i.e. compositing it cannot change a single bit of
@@ -470,10 +481,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 int vi, vj, vk;
                 if (POW2) {
                     // voxel units: Q = q*S, U = Q + half*S = texcoord*S before the flips
-                    const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+                    const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
                     float fx = ux, fy = uy, fz = uz;
-                    if (VIEW == 1) { fy = Sz - uz; fz = uy; }
-                    else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                    if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                    else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                     vi = (int)fx; vj = (int)fy; vk = (int)fz;
                     Qx += dSx; Qy += dSy; Qz += dSz;
                 } else {
@@ -734,6 +745,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     float Qx = qx * Sx, Qy = qy * Sy, Qz = qz * Sz;          // POW2: voxel-unit marching (see the fast kernel)
     const float dSx = dsx * Sx, dSy = dsy * Sy, dSz = dsz * Sz;
     const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+    // (in VECTOR registers for the sample loop: a VALU instruction with an SGPR operand issues at the slow rate on gfx950, 4.2
+    // cycles instead of 2.3 -- fp32 and integer alike, tools/ubench/valu_rates2.hip)
+    float Szv = Sz, Syv = Sy;
+    asm volatile("" : "+v"(Szv), "+v"(Syv));
     auto scaled_texcoord = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
         const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
         const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
@@ -815,10 +830,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         for (int u = 0; u < TRI_BATCH; u++) {
             float fx, fy, fz;
             if (POW2) {
-                const float ux = Qx + Hx, uy = Qy + Hy, uz = Sz - (Qz + Hz);
+                const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
                 fx = ux; fy = uy; fz = uz;
-                if (VIEW == 1) { fy = Sz - uz; fz = uy; }
-                else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                 Qx += dSx; Qy += dSy; Qz += dSz;
             } else {
                 scaled_texcoord(qx, qy, qz, fx, fy, fz);
@@ -1080,6 +1095,10 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     const float Sx = P.fdim[0], Sy = VIEW == 0 ? P.fdim[1] : P.fdim[2], Sz = VIEW == 0 ? P.fdim[2] : P.fdim[1];
     const float mx = POW2 ? dsx * Sx : dsx, my = POW2 ? dsy * Sy : dsy, mz = POW2 ? dsz * Sz : dsz;
     const float Hx = P.half[0] * Sx, Hy = P.half[1] * Sy, Hz = P.half[2] * Sz;
+    // (in VECTOR registers for the sample loop: a VALU instruction with an SGPR operand issues at the slow rate on gfx950, 4.2
+    // cycles instead of 2.3 -- fp32 and integer alike, tools/ubench/valu_rates2.hip)
+    float Szv = Sz, Syv = Sy;
+    asm volatile("" : "+v"(Szv), "+v"(Syv));
     const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
 
     // The ray positions travel the same way as the compositing state: the wavefront that
@@ -1115,10 +1134,10 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             for (int u = 0; u < RELAY_BATCH; u++) {
                 int vi, vj, vk;
                 if (POW2) {
-                    const float ux = x + Hx, uy = y + Hy, uz = Sz - (z + Hz);
+                    const float ux = x + Hx, uy = y + Hy, uz = Szv - (z + Hz);
                     float fx = ux, fy = uy, fz = uz;
-                    if (VIEW == 1) { fy = Sz - uz; fz = uy; }
-                    else if (VIEW == 2) { fy = uz; fz = Sy - uy; }
+                    if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                    else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                     vi = (int)fx; vj = (int)fy; vk = (int)fz;
                 } else {
                     const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
