@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         plan_b = ring - (ptrdiff_t)Llo * plan_stride;                    // plan entry of layer L (Llo <= L <= Lhi) at plan_b + L * plan_stride
         if (stage && any_prefix && plan_bytes <= C::REGION / 2) {
             int m_bb = 0;                                                // widest bounding rectangle (its extent must fit the entry's 8 bits)
-            int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1, m_low = 0;
+            int m_dda = 0, m_ddb = 0, m_loa = 0x7fffffff, m_hia = -1, m_lob = 0x7fffffff, m_hib = -1;
             for (int L = Llo + (int)threadIdx.x; L <= Lhi; L += TS_THREADS) {
                 float pa[8], pb[8];
                 layer_points(L, pa, pb);
@@ -514,12 +514,11 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                 m_bb = max(m_bb, dda);
                 m_dda = max(m_dda, width); m_ddb = max(m_ddb, ddb);      // every planned layer is one some phase reads or prefetches
                 m_loa = min(m_loa, lo_a); m_hia = max(m_hia, hi_a); m_lob = min(m_lob, lo_b); m_hib = max(m_hib, hi_b);
-                if (amin - delta < 1.0f || bmin - delta < 1.0f) m_low = 1;   // some ray comes within a voxel of a low face
             }
-            m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_low = wave_max_i(m_low); m_bb = wave_max_i(m_bb);
+            m_dda = wave_max_i(m_dda); m_ddb = wave_max_i(m_ddb); m_bb = wave_max_i(m_bb);
             m_loa = wave_min_i(m_loa); m_hia = wave_max_i(m_hia); m_lob = wave_min_i(m_lob); m_hib = wave_max_i(m_hib);
             if (lane == 0) {
-                atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicOr(&red[5], m_low); atomicMax(&red[10], m_bb);
+                atomicMax(&red[3], m_dda); atomicMax(&red[4], m_ddb); atomicMax(&red[10], m_bb);
                 atomicMin(&red[6], m_loa); atomicMax(&red[7], m_hia); atomicMin(&red[8], m_lob); atomicMax(&red[9], m_hib);
             }
         }
@@ -767,7 +766,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         // sample may lie outside the box: its look-ups and taps read whatever LDS holds there -- out-of-range LDS reads
         // return zero -- and are never composited.)
         float tx = 0.0f, ty = 0.0f, tz = 0.0f;
-        auto prepare = [&](auto) {
+        auto prepare = [&]() {
             float fx, fy, fz;
             scaled_here(fx, fy, fz);
             ux = fx - 0.5f; uy = fy - 0.5f; uz = fz - 0.5f;
@@ -784,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         };
         auto sat_sub = [](float a, float b) { float r; asm("v_sub_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; };
         auto weights = [&]() { wx = sat_sub(ux, tx); wy = sat_sub(uy, ty); wz = sat_sub(uz, tz); };
-        prepare(std::true_type{}); weights();
+        prepare(); weights();
         // samples of the prefix taken so far / to take, as floats: the per-sample bookkeeping is then one fp32 add
         const bool ahead_ok = LA >= 2;
         float takenf = 0.0f;
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // The single instance always clamps (three v_max, 13 cycles per iteration: less than the copies cost).
             // Not available on this chip: d16 LDS loads into registers whose high halves hold 0x4B00 (the register would BE
             // the float 2^23 + v, no conversion): with SRAM ECC the hardware zeroes the unused half (tools/ubench/d16_preserve.hip))
-            auto phase_samples = [&](auto clamp_tag) {
+            auto phase_samples = [&]() {
                 bool alive = takenf < limitf && da < 0.95f;
                 bool here = alive && lay == L + LAY_BIAS;
                 if (__any(here ? 1 : 0)) do {
@@ -836,7 +835,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
                     else { qx = __builtin_fmaf(dsx, vf, qx); qy = __builtin_fmaf(dsy, vf, qy); qz = __builtin_fmaf(dsz, vf, qz); }
                     takenf += vf;
-                    prepare(clamp_tag);
+                    prepare();
                     const float ax = wx, ay = wy, az = wz;
                     float c00, c10, c01, c11;
                     if (sizeof(VoxelT) == 1) {
@@ -875,7 +874,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     here = alive && lay == L + LAY_BIAS;
                 } while (__any(here ? 1 : 0));
             };
-            phase_samples(std::true_type{});
+            phase_samples();
             // ---- what the next phase reads must have landed before its barrier: with one phase of prefetch distance
             // that is the layer just requested, with two it was requested a phase ago
             slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
