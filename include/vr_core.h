@@ -163,8 +163,9 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    own major axis with unit-stride DMA pieces) and the layer thickness chosen per tile: whole brick layers where they fit the tile's
    LDS ring, half layers (two voxels, 80-byte slots) where they do not -- 8 on 32x16-pixel tiles, 9 on 16x32-pixel tiles whose ring
    can also hold, per brick row, that row's own range (tiles whose bounding rectangles fit no other way: views near a body
-   diagonal).  16-bit volumes; on 8-bit ones 8 runs as 6 and 9 as 6 on 16x32-pixel tiles.  (10 / 11, the whole-LDS shapes round 4
-   measured and did not keep, are refused.)
+   diagonal).  16-bit volumes; on 8-bit ones 8 runs as 6 and 9 as 6 on 16x32-pixel tiles.
+   10 = the shape of 6 on 53 KiB of LDS: three workgroups per CU, six wavefronts per SIMD -- faster (6-13 %) wherever the tiles' brick
+   layers fit (8-bit volumes, 16-bit ones up to ~512^3 or at 4K), slower where they do not; a candidate of the measured choice.
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): under kernel variant 0 the launch is a MEASURED choice -- every candidate kernel of a configuration
@@ -177,7 +178,7 @@ int vr_set_kernel_variant(vr_handle h, int variant);
 int vr_set_autotune(vr_handle h, int enable);
 /* what the last launch ran as (for tests and tools; no reference equivalent): bit 0 relay kernel, bit 1 pipelined batch loop,
    bit 2 four-sample batches, bits 3..6 the LDS-staged trilinear kernel's shape (0 = not that kernel; the numbers of
-   vr_set_kernel_variant 6 .. 9 minus 5) */
+   vr_set_kernel_variant 6 .. 10 minus 5) */
 int vr_get_launch_choice(vr_handle h);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %

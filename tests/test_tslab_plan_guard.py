@@ -4,7 +4,7 @@ lib/libvr_core_chk.so is the library with vr_tslab.hip compiled under -DVR_TSLAB
 that the bricks of its four tap pairs lie inside the rectangle their layer was planned and loaded with, in a layer that is resident
 in the current phase, and reports the violations per pixel in place of the fetch count.  A worker process loads that build
 (VR_CORE_LIB) and sweeps volume shapes x spacings (steps of 0.3 ... 2.5 voxels along an axis) x voxel types x cameras (orbit,
-pole, inside, close, eye 6 and 15 units away, random) x every staged shape (kernel variants 6, 8, 9) x the rotated views, and
+pole, inside, close, eye 6 and 15 units away, random) x every staged shape (kernel variants 6, 8, 9, 10) x the rotated views, and
 the 1024^3 u16 workload at 1080p: zero violations, and the staged path must actually have run."""
 import json
 import os

@@ -34,7 +34,7 @@ def test_a_cold_renderer_ends_on_the_sweeps_choice(vra, case):
         forced = (2, 5, 3)
         if case == "trilinear_oblique_u16":
             r.setFilter(R.FILTER_TRILINEAR); r.cameraOrient(0.0, 0.66, -1.65)
-            forced = (2, 6, 8, 9)
+            forced = (2, 6, 8, 9, 10)
         elif case == "nearest_shard8":
             r.setRowStripes(16, 3, 8)
         for _ in range(300):                                     # a cold start: exploration, settling, the one re-validation

@@ -22,11 +22,11 @@ cp profiles/traffic.json $OUT/traffic.json; cp profiles/valu.json $OUT/valu.json
 python bench.py --extras > $OUT/bench.json 2> $OUT/bench.err
 python bench.py --native-group --gpus 4 --steps 50 > $OUT/bench_native_group4.json 2>&1
 VR_BENCH_BACKEND=gloo python bench.py --gpus 4 --steps 50 > $OUT/bench_torch_gloo4.json 2>&1
-# TRILINEAR over orbit poses: batched kernel (2), LDS-staged kernel whole layers (6), layer thickness per tile on 32x16- (8) and 16x32-pixel tiles with rows (9), the measured choice (0); cfg4 (6 vs generic)
-{ for v in 2 6 9 0; do echo "1024^3 x 1 B, kernel variant $v: $(timeout 300 python tools/tri_ms.py $v orbit6 1024 1 2>&1 | tail -1)"; done
-  for v in 2 6 8 9 0; do echo "1024^3 x 2 B, kernel variant $v: $(timeout 300 python tools/tri_ms.py $v orbit6 1024 2 2>&1 | tail -1)"; done
+# TRILINEAR over orbit poses: batched kernel (2), LDS-staged kernel whole layers (6), layer thickness per tile on 32x16- (8) and 16x32-pixel tiles with rows (9), three workgroups per CU (10), the measured choice (0); cfg4 (6 vs generic)
+{ for v in 2 6 9 10 0; do echo "1024^3 x 1 B, kernel variant $v: $(timeout 300 python tools/tri_ms.py $v orbit6 1024 1 2>&1 | tail -1)"; done
+  for v in 2 6 8 9 10 0; do echo "1024^3 x 2 B, kernel variant $v: $(timeout 300 python tools/tri_ms.py $v orbit6 1024 2 2>&1 | tail -1)"; done
   for v in 2 6 8 9 0; do echo "1024^3 x 2 B, default + off-axis (zenith 60, azimuth 45), kernel variant $v: $(timeout 300 python tools/tri_ms.py $v both 1024 2 2>&1 | tail -1)"; done
-  for v in 6 1; do echo "2048^3 x 1 B @3840x2160, kernel variant $v: $(timeout 600 python tools/tri_ms.py $v orbit4 2048 1 2>&1 | tail -1)"; done; } > $OUT/${TAG}_trilinear_orbit.txt 2>&1
+  for v in 6 10 1; do echo "2048^3 x 1 B @3840x2160, kernel variant $v: $(timeout 600 python tools/tri_ms.py $v orbit4 2048 1 2>&1 | tail -1)"; done; } > $OUT/${TAG}_trilinear_orbit.txt 2>&1
 # randomised stress campaign (tests/test_parity_gpu.py: run_random_trials; every frame against the CPU oracle)
 timeout 900 python tools/stress_campaign.py 60000 304 2>&1 | tail -2 > $OUT/${TAG}_stress_campaign.txt
 tail -c 2500 $OUT/bench.json

@@ -622,8 +622,8 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    // kernel variants 6 .. 9: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
-    L.tri_slab = (force_generic >= 6 && force_generic <= 9) ? force_generic - 5 : 0;
+    // kernel variants 6 .. 10: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
+    L.tri_slab = (force_generic >= 6 && force_generic <= 10) ? force_generic - 5 : 0;
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -774,6 +774,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         // TRILINEAR: the LDS-staged kernel in its shapes, the batched kernel where it can run
         add(prior);
         add(1 << 3);
+        add(5 << 3);                                                     // three workgroups per CU: wins where the tiles' layers fit 53 KiB
         if (tri_path_candidate(P, L)) add(0);
         if (L.apron_y != nullptr && L.apron_x != nullptr) {
             add(3 << 3);

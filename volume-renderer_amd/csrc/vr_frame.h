@@ -88,7 +88,7 @@ struct LaunchConfig {
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     const void *apron_y, *apron_x; // device: the apron copy with the bricks' planes along y / x slowest (orders 1 and 2 of relayout_apron_kernel; nullptr = none): half layers of the staged kernel
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16-pixel tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 3 = 16-bit volumes: per-axis copies and the layer thickness per tile (variant 8); 4 = 16x32-pixel tiles with rows (variant 9; 16-bit volumes as 3, 8-bit ones with whole layers)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16-pixel tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 3 = 16-bit volumes: per-axis copies and the layer thickness per tile (variant 8); 4 = 16x32-pixel tiles with rows (variant 9; 16-bit volumes as 3, 8-bit ones with whole layers); 5 = as 1 on 53 KiB, three workgroups per CU (variant 10)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

@@ -58,8 +58,11 @@ namespace vr {
 // Workgroup shapes (template parameters NW = wavefronts, LDSKB = KiB of LDS the workgroup declares, TW = wavefronts per tile row):
 //   NW = 8, LDSKB = 80 is what ships: one 32x16- or 16x32-pixel tile per workgroup, two workgroups per CU.  The ring holds three
 //   144-slot layers of 160 B for the 1024^3 u16 workload at 1080p; u8 slots are half as large, but a 2048^3 volume's plan + tables
-//   take 20 KiB.  Three workgroups per CU (53 KiB, 24 wavefronts) measured the SAME time on a workload whose layers fit (512^3: 0.711
-//   vs 0.713 ms) -- but ONE workgroup per CU (8 wavefronts on the whole 160 KiB) is 1.5x slower (1.25 -> 1.86 ms): two wavefronts
+//   take 20 KiB.  NW = 8, LDSKB = 53 ships too (round 4, tri_slab 5): THREE workgroups per CU, six wavefronts per SIMD at 80 VGPRs (43
+//   dwords spilled, none in the sample loop).  In round 3 it measured the same time as two (512^3: 0.711 vs 0.713 ms, the loop was
+//   bound by VALU issue); with round 4's cheaper loop the extra wavefronts cover the LDS round trips: 512^3 u16 0.520 -> 0.452 ms,
+//   1024^3 u8 1.061 -> 0.932, the cfg2 shape 0.445 -> 0.417 -- where a tile's layers fit 53 KiB; where they do not (1024^3 u16:
+//   1.14 -> 1.84) the work model keeps the 80-KiB shapes.  ONE workgroup per CU (8 wavefronts on the whole 160 KiB) is 1.5x slower (1.25 -> 1.86 ms): two wavefronts
 //   per SIMD do not cover each other's LDS round trips.  16 wavefronts on a 32x32-pixel tile and the whole LDS: + 10 % at the
 //   default pose, and a frame is three rounds of long tiles.  Both whole-LDS shapes were measured with whole and half layers
 //   (round 4) and are not instantiated any more; the parameters stay.
@@ -71,7 +74,7 @@ template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM, int TW = 4>
 struct TslabCfg {
     static constexpr int THREADS = 64 * NW;                                       // TW x NW/TW wavefronts of 8x8 pixels
     static constexpr int TILE_W = 8 * TW, TILE_H = 8 * (NW / TW);
-    static constexpr int WAVES_PER_SIMD = (LDSKB <= 80 ? 2 : 1) * NW / 4;
+    static constexpr int WAVES_PER_SIMD = (LDSKB <= 53 ? 3 : (LDSKB <= 80 ? 2 : 1)) * NW / 4;   // workgroups per CU: 3 / 2 / 1
     static constexpr int BRICK_BYTES = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // a brick of the apron copies: 80 B (u8) / 160 B (u16)
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
     static constexpr int MISC_BYTES = 512;
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
 }
 
 // ------------------------------------------------------------------ dispatch
-// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4: u8; 1 .. 3: u16 (below)
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4 / 6: u8; 1 .. 3, 5: u16 (below)
 template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
 static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                uint32_t *spp, hipStream_t st)
@@ -1052,17 +1055,20 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
 }
 
 #define VR_TSLAB_ARGS const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb, uint32_t *spp, hipStream_t st
-// By workgroup shape (LaunchConfig::tri_slab; vr_set_kernel_variant 6 .. 9):
+// By workgroup shape (LaunchConfig::tri_slab; vr_set_kernel_variant 6 .. 10):
 //   tri_slab 1 (2 = staging off): 32x16-pixel tiles, 80 KiB, order-0 copy, whole layers (8- and 16-bit volumes)
 //   tri_slab 3: 16-bit volumes, the same tiles with the per-axis copies, layer thickness per tile (half layers where whole ones do not fit)
 //   tri_slab 4: 16x32-pixel tiles (two wavefronts wide, four tall), rows for the tiles that fit no other way; 16-bit volumes with
 //               the per-axis copies and the thickness per tile, 8-bit ones with whole layers
+//   tri_slab 5: the shape of 1 on 53 KiB, three workgroups per CU (8- and 16-bit volumes)
 // (round 4 also measured, and did not keep: whole layers only on a CU's whole LDS -- 32x16 tiles 1.96-2.13 ms over the orbit poses,
 // 32x32 tiles with 16 wavefronts 1.64-3.6 --; half layers on 32x32 tiles / 160 KiB 1.63-1.89, off-axis 2.73; half layers on 32x16 tiles
 // with the whole LDS 1.90-2.06, off-axis 2.39: behind the two shapes above at every pose once the 16x32 tiles had rows)
 hipError_t launch_tslab_u16_half(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_three(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u8_three(VR_TSLAB_ARGS);
 
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
@@ -1071,6 +1077,7 @@ hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);
 hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS)
 {
     if (L.tri_slab == 4 && L.tile_table_tall != nullptr) return launch_tslab_u8_tall(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 5) return launch_tslab_u8_three(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -1080,6 +1087,7 @@ hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
     const bool perm_ok = L.apron_y != nullptr && L.apron_x != nullptr;
     if (L.tri_slab == 3 && perm_ok) return launch_tslab_u16_half(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 4 && perm_ok && L.tile_table_tall != nullptr) return launch_tslab_u16_halftall(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 5) return launch_tslab_u16_three(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint16_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -1091,6 +1099,12 @@ hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS) { return dispatch_tslab<uint
 #endif
 #if VR_TSLAB_TU == 4 || VR_TSLAB_TU == -1
 hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 80, false, 2>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 5 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 8, 53, false>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 6 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u8_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 53, false>(P, L, vol, tf, fb, spp, st); }
 #endif
 
 }  // namespace vr
