@@ -39,6 +39,7 @@ class _Params(C.Structure):
         ("filter", C.c_int32), ("accum", C.c_int32), ("max_steps", C.c_int32),
         ("tf_rgba", C.POINTER(C.c_float)), ("tf_len", C.c_int32),
         ("threads", C.c_int32),
+        ("arith", C.c_int32),
     ]
 
 
@@ -115,6 +116,7 @@ class OracleParams:
     row_end: int = -1
     tf_rgba: np.ndarray | None = None
     threads: int = 1
+    arith: int = 0          # 0 = MESA (the executed reference: the contract), 1 = SPEC (specification text)
 
 
 def render(volume: np.ndarray, p: OracleParams, want_spp: bool = False, out: np.ndarray | None = None):
@@ -146,6 +148,7 @@ def render(volume: np.ndarray, p: OracleParams, want_spp: bool = False, out: np.
         q.tf_rgba = tf.ctypes.data_as(C.POINTER(C.c_float))
         q.tf_len = tf.shape[0]
     q.threads = p.threads
+    q.arith = p.arith
     rgba = out if out is not None else np.zeros((p.img_h, p.img_w, 4), dtype=np.float32)
     spp = np.zeros((p.img_h, p.img_w), dtype=np.uint32) if want_spp else None
     total = C.c_uint64()

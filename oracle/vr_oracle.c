@@ -1,5 +1,6 @@
 /*
- * vr_oracle.c -- TEST INFRASTRUCTURE ONLY (see vr_oracle.h).  PARITY UNPINNED.
+ * vr_oracle.c -- TEST INFRASTRUCTURE ONLY (see vr_oracle.h).  Parity pinned to the reference
+ * shader executed under Mesa llvmpipe (tests/golden/ref_gl_*.npz), bit for bit.
  *
  * Scalar fp32 restatement of /root/reference/VolumeRenderer.cs, one function per
  * shader function, keeping the shader's operation order.  Build with
@@ -8,12 +9,14 @@
  * the HIP kernel is held to (tests compare bit patterns, the 1e-4 tolerance of
  * BASELINE.json is the fallback bar).
  *
- * GLSL built-ins are restated by their specification text:
+ * GLSL operators are one correctly rounded operation each (measured on the pinned GL:
+ * a/b is the correctly rounded quotient, a*b+c is never contracted).  Built-ins:
  *   min(x,y) = y<x ? y : x        max(x,y) = x<y ? y : x
  *   clamp(x,a,b) = min(max(x,a),b)
- *   length(v) = sqrt(v.x*v.x + v.y*v.y + ...)   (left-to-right sum)
- *   normalize(v) = v / length(v)
  *   M*v = ((M[0]*v.x + M[1]*v.y) + M[2]*v.z) + M[3]*v.w
+ *   dot / length / normalize: two models, see VRO_ARITH_* in vr_oracle.h --
+ *     MESA (default)  dot summed last component to first; normalize(v) = v * (1/sqrt(dot))
+ *     SPEC            dot summed first to last;            normalize(v) = v / sqrt(dot)
  * texture() on the integer volume is NEAREST with CLAMP_TO_EDGE:
  *   i = clamp(int(floor(u*N)), 0, N-1)          (RendererCore.cpp:408-419)
  * TRILINEAR (north-star mode, no reference semantics) is GL's linear rule:
@@ -35,11 +38,26 @@ static inline float gl_min(float x, float y) { return (y < x) ? y : x; }
 static inline float gl_max(float x, float y) { return (x < y) ? y : x; }
 static inline float gl_clamp(float x, float lo, float hi) { return gl_min(gl_max(x, lo), hi); }
 
-static inline v4 v4_normalize(v4 v)
+/* normalize(): VRO_ARITH_SPEC = the specification text, v / sqrt(left-to-right dot);
+   VRO_ARITH_MESA (default) = what Mesa's GLSL compiler emits and llvmpipe executes (measured by
+   oracle/ref_gl/probe_arith.py): v * (1 / sqrt(dot)), dot summed from the LAST component
+   to the first (NIR's fdot lowering).  Each op is still one correctly rounded binary32 op. */
+static inline v4 v4_normalize(v4 v, int arith)
 {
+    if (arith == VRO_ARITH_MESA) {
+        float rs = 1.0f / sqrtf(((v.w * v.w + v.z * v.z) + v.y * v.y) + v.x * v.x);
+        v4 m = { v.x * rs, v.y * rs, v.z * rs, v.w * rs };
+        return m;
+    }
     float len = sqrtf(((v.x * v.x + v.y * v.y) + v.z * v.z) + v.w * v.w);
     v4 r = { v.x / len, v.y / len, v.z / len, v.w / len };
     return r;
+}
+
+/* length(vec3(a,b,c)) in the two arithmetic models (see v4_normalize) */
+static inline float v3_length(float a, float b, float c, int arith)
+{
+    return arith == VRO_ARITH_MESA ? sqrtf((c * c + b * b) + a * a) : sqrtf((a * a + b * b) + c * c);
 }
 
 /* per-frame constants: main() lines 62-83 of VolumeRenderer.cs */
@@ -73,10 +91,9 @@ static void frame_setup(const vro_params *p, frame_consts *fc)
     /* :109 length(p_max-p_min) / length(vec3(vol_size.xzy))   (composite)
        :146 length(p_max-p_min) / length(vec3(vol_size.xyz))   (MIP)        */
     float e0 = fc->pmax[0] - fc->pmin[0], e1 = fc->pmax[1] - fc->pmin[1], e2 = fc->pmax[2] - fc->pmin[2];
-    float num = sqrtf((e0 * e0 + e1 * e1) + e2 * e2);
+    float num = v3_length(e0, e1, e2, p->arith);
     float fx = (float)p->nx, fy = (float)p->ny, fz = (float)p->nz;
-    float den = p->is_mip == 1 ? sqrtf((fx * fx + fy * fy) + fz * fz)
-                               : sqrtf((fx * fx + fz * fz) + fy * fy);
+    float den = p->is_mip == 1 ? v3_length(fx, fy, fz, p->arith) : v3_length(fx, fz, fy, p->arith);
     fc->step = num / den;
     fc->fmin = (float)p->min_val;
     fc->fmax = (float)p->max_val;
@@ -93,13 +110,13 @@ static void compute_ray(const vro_params *p, float pixel_x, float pixel_y, v4 *o
     float y = ((2.0f * pixel_y) / fh) - 1.0f;
     float z = -c[20];
     v4 d = { x, y, z, 0.0f };
-    d = v4_normalize(d);
+    d = v4_normalize(d, p->arith);
     v4 m;
     m.x = ((c[0] * d.x + c[4] * d.y) + c[8] * d.z) + c[12] * d.w;
     m.y = ((c[1] * d.x + c[5] * d.y) + c[9] * d.z) + c[13] * d.w;
     m.z = ((c[2] * d.x + c[6] * d.y) + c[10] * d.z) + c[14] * d.w;
     m.w = ((c[3] * d.x + c[7] * d.y) + c[11] * d.z) + c[15] * d.w;
-    *dir = v4_normalize(m);
+    *dir = v4_normalize(m, p->arith);
     origin->x = c[16]; origin->y = c[17]; origin->z = c[18]; origin->w = c[19];
 }
 
@@ -129,8 +146,11 @@ static inline void cartesian_to_texcoord(const vro_params *p, const frame_consts
 {
     px = px + fc->half[0]; py = py + fc->half[1]; pz = pz + fc->half[2];
     px = px / fc->ext[0];  py = py / fc->ext[1];  pz = pz / fc->ext[2];
+    /* :185-187.  view_top reads 1 - (1 - z): Mesa's algebraic pass folds that to z
+       (nir_opt_algebraic, a + -(a + b) -> -b; seen as 4 pixels of a 256x256 top view). */
+    float pz_in = pz;
     pz = 1.0f - pz;
-    if (p->view_top == 1) { tc[0] = px; tc[1] = 1.0f - pz; tc[2] = py; }
+    if (p->view_top == 1) { tc[0] = px; tc[1] = (p->arith == VRO_ARITH_MESA) ? pz_in : 1.0f - pz; tc[2] = py; }
     else if (p->view_bottom == 1) { tc[0] = px; tc[1] = pz; tc[2] = 1.0f - py; }
     else { tc[0] = px; tc[1] = py; tc[2] = pz; }
 }

@@ -8,10 +8,16 @@
  * path and the timed CPU baseline of bench.py; nothing in the product
  * (volume-renderer_amd/, include/) may include, link or call it.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or CPU
- * implementation of this path, and its GLSL cannot be executed in the authoring
- * container (no GL context / GLSL compiler).  The oracle is therefore pinned only
- * by analytic known-answer tests (tests/test_oracle_kat.py); see DESIGN.md.
+ * PARITY PINNED (round 5): the reference's unmodified shader is executed in the
+ * authoring container by Mesa 23.2.1 llvmpipe through oracle/ref_gl/ref_gl_runner.c
+ * (a DRI-swrast loader; real GLSL compiler, real texture unit emulation), with the
+ * reference's own GL call sequence; the frames are committed as
+ * tests/golden/ref_gl_*.npz and this oracle reproduces every one of them bit for bit
+ * (tests/test_ref_gl_goldens.py).  One stated deviation when minting: MIN/MAG filter
+ * GL_NEAREST instead of the reference's GL_LINEAR, because with GL_LINEAR the integer
+ * texture is incomplete and the reference renders all zeros on a conformant GL
+ * (measured) -- Mesa's own app-compat switch force_integer_tex_nearest
+ * gives the same frames with the reference's calls untouched.
  */
 #ifndef VR_ORACLE_H
 #define VR_ORACLE_H
@@ -23,6 +29,20 @@ extern "C" {
 
 enum { VRO_FILTER_NEAREST = 0, VRO_FILTER_TRILINEAR = 1 };
 enum { VRO_ACCUM_ITERATIVE = 0, VRO_ACCUM_CLOSED_FORM = 1 };
+/* Rounding model of the GLSL built-ins normalize()/length()/dot() and of one algebraic
+   fold (everything else is one correctly rounded binary32 op per GLSL operator in both):
+     MESA  (default, the contract) what Mesa 23.2.1's GLSL compiler emits for the
+           reference shader and llvmpipe executes, measured op by op with
+           oracle/ref_gl/probe_arith.py: normalize(v) = v * (1/sqrt(dot)), dot summed
+           last component to first, and view_top's 1-(1-z) folded to z.  In this mode
+           the oracle reproduces the reference shader run under that GL BIT FOR BIT on
+           every golden frame (tests/test_ref_gl_goldens.py); the HIP kernels are held
+           to it bit for bit.
+     SPEC  the GLSL specification text read literally: normalize(v) = v / sqrt(dot),
+           dot summed first to last, no folding.  Kept to measure how far a different
+           conformant GL may land from the pinned one (lattice-degenerate rays flip a
+           voxel: ~0.05 % of cfg2's pixels move by more than 1e-4). */
+enum { VRO_ARITH_MESA = 0, VRO_ARITH_SPEC = 1 };
 
 typedef struct vro_params {
     /* image (imageSize(render_texture), VolumeRenderer.cs:57) */
@@ -54,6 +74,7 @@ typedef struct vro_params {
     const float *tf_rgba;
     int32_t tf_len;
     int32_t threads;                   /* <=1: scalar single thread; >1: OpenMP rows */
+    int32_t arith;                     /* VRO_ARITH_* */
 } vro_params;
 
 /* Renders into rgba (img_h*img_w*4 floats, row 0 = bottom, GL convention).

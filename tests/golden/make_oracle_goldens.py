@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Mint regression goldens of the CPU oracle for BASELINE configs 0-2.
 
-The reference has no golden vectors for the ray-march (it is GLSL and cannot run here), so
-these do NOT pin the oracle to the reference -- the analytic KATs do what can be done there.
-They freeze the oracle's own answers so that a later edit of oracle/vr_oracle.c (or of the
-generators) cannot drift unnoticed, and they give the GPU tests a fixture that travels.
+These do NOT pin the oracle to the reference -- tests/golden/ref_gl/ does that (the reference's shader
+executed under Mesa llvmpipe, oracle/ref_gl/mint_ref_gl_goldens.py).  They freeze the oracle's own
+answers, including TRILINEAR (no reference semantics) and sample counts, so that a later edit of
+oracle/vr_oracle.c (or of the generators) cannot drift unnoticed, and they give the GPU tests a
+fixture that travels.
 
 cfg0: the full 256x256 frame; cfg1/cfg2 shapes: every K-th image row of the full-size frame.
 Run from the repo root:  python tests/golden/make_oracle_goldens.py

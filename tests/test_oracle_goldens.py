@@ -2,8 +2,11 @@
 tests/golden/make_oracle_goldens.py): BASELINE configs 0-2 at reduced probes.
 
 CPU: the oracle still gives the frozen answers.  GPU: the HIP path, through the C ABI, gives the
-same bits for the same rows.  These are NOT reference vectors (the reference has none for this
-path) -- they keep oracle and kernels from drifting together or apart between rounds.
+same bits for the same rows.  These are NOT reference vectors -- those are tests/golden/ref_gl/ (the reference's
+shader executed by a real GL, tests/test_ref_gl_goldens.py).  These freeze the oracle's answers where the reference
+has no semantics to execute (TRILINEAR) and its per-pixel fetch counts, so oracle and kernels cannot drift
+together or apart between rounds.  Re-minted in round 5 when the oracle adopted the executed reference's
+arithmetic (normalize / dot order); the cfg0 frame hashes now equal the reference's own.
 """
 import hashlib
 import importlib.util

@@ -602,9 +602,11 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     }
     // ---- step_size: VolumeRenderer.cs:109 (composite, .xzy) / :146 (MIP, .xyz)
     const float e0 = P.pmax[0] - P.pmin[0], e1 = P.pmax[1] - P.pmin[1], e2 = P.pmax[2] - P.pmin[2];
-    const float num = std::sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+    // length(vec3) = sqrt of the dot summed from the last component to the first, as the reference's GL executes it
+    // (oracle/ref_gl/probe_arith.py); .xzy in rayMarchVolume, .xyz in MIP
+    const float num = std::sqrt((e2 * e2 + e1 * e1) + e0 * e0);
     const float fx = (float)nx, fy = (float)ny, fz = (float)nz;
-    const float den = u_.is_MIP == 1 ? std::sqrt((fx * fx + fy * fy) + fz * fz) : std::sqrt((fx * fx + fz * fz) + fy * fy);
+    const float den = u_.is_MIP == 1 ? std::sqrt((fz * fz + fy * fy) + fx * fx) : std::sqrt((fy * fy + fz * fz) + fx * fx);
     P.step = num / den;
     P.alpha_scale = u_.alpha_scale;
     P.min_val = u_.min_val; P.max_val = u_.max_val;

@@ -65,7 +65,10 @@ __device__ __forceinline__ void store_pixel(const FrameParams &P, float4 *__rest
 
 struct Ray { float ox, oy, oz, dx, dy, dz; };
 
-// VolumeRenderer.cs:194-216
+// VolumeRenderer.cs:194-216.  normalize() is what the GLSL compiler makes of it and the reference's GL executes
+// (Mesa 23.2.1, measured by oracle/ref_gl/probe_arith.py and pinned by tests/golden/ref_gl_*.npz):
+//   normalize(v) = v * (1 / sqrt(dot(v, v))),  dot summed from the LAST component to the first;
+// mat4 * vec4 is the column chain ((c0*x + c1*y) + c2*z) + c3*w.  Each operation one rounding.
 __device__ __forceinline__ Ray compute_ray(const FrameParams &P, float pixel_x, float pixel_y)
 {
     const float *c = P.cam;
@@ -75,15 +78,15 @@ __device__ __forceinline__ Ray compute_ray(const FrameParams &P, float pixel_x, 
     const float y = ((2.0f * pixel_y) / fh) - 1.0f;
     const float z = -c[20];
     const float w = 0.0f;
-    float len = sqrtf(((x * x + y * y) + z * z) + w * w);
-    const float dx = x / len, dy = y / len, dz = z / len, dw = w / len;
+    float rs = 1.0f / sqrtf(((w * w + z * z) + y * y) + x * x);
+    const float dx = x * rs, dy = y * rs, dz = z * rs, dw = w * rs;
     const float mx = ((c[0] * dx + c[4] * dy) + c[8] * dz) + c[12] * dw;
     const float my = ((c[1] * dx + c[5] * dy) + c[9] * dz) + c[13] * dw;
     const float mz = ((c[2] * dx + c[6] * dy) + c[10] * dz) + c[14] * dw;
     const float mw = ((c[3] * dx + c[7] * dy) + c[11] * dz) + c[15] * dw;
-    len = sqrtf(((mx * mx + my * my) + mz * mz) + mw * mw);
+    rs = 1.0f / sqrtf(((mw * mw + mz * mz) + my * my) + mx * mx);
     Ray r;
-    r.dx = mx / len; r.dy = my / len; r.dz = mz / len;
+    r.dx = mx * rs; r.dy = my * rs; r.dz = mz * rs;
     r.ox = c[16]; r.oy = c[17]; r.oz = c[18];
     return r;
 }

@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
             } else {
                 ux = ux / P.ext[0]; uy = uy / P.ext[1]; uz = uz / P.ext[2];
             }
+            const float uzr = uz;   // z before the flip of :185
             uz = 1.0f - uz;
             float tcx, tcy, tcz;
-            if (P.view_top == 1) { tcx = ux; tcy = 1.0f - uz; tcz = uy; }
+            if (P.view_top == 1) { tcx = ux; tcy = uzr; tcz = uy; }   // 1 - (1 - z) as the GL compiles it: z
             else if (P.view_bottom == 1) { tcx = ux; tcy = uz; tcz = 1.0f - uy; }
             else { tcx = ux; tcy = uy; tcz = uz; }
             if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || d3 >= 0.95f)
@@ -360,10 +361,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         auto voxel_of = [&](float ax, float ay, float az, int &vi, int &vj, int &vk) {
             const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
+            const float uzr = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }          // view_top
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }          // view_top
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }     // view_bottom
             vi = (int)(tcx * P.fdim[0]);
             vj = (int)(tcy * P.fdim[1]);
@@ -423,9 +424,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             // affine map position -> voxel coordinate per voxel axis (flips included)
             auto to_voxel = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
                 const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
-                const float uz = 1.0f - (az + P.half[2]) * P.rext[2];
+                const float uzr = (az + P.half[2]) * P.rext[2], uz = 1.0f - uzr;
                 float tcx = ux, tcy = uy, tcz = uz;
-                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                if (VIEW == 1) { tcy = uzr; tcz = uy; }
                 else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
                 fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
             };
@@ -481,9 +482,9 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                 int vi, vj, vk;
                 if (POW2) {
                     // voxel units: Q = q*S, U = Q + half*S = texcoord*S before the flips
-                    const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
+                    const float ux = Qx + Hx, uy = Qy + Hy, uzr = Qz + Hz, uz = Szv - uzr;
                     float fx = ux, fy = uy, fz = uz;
-                    if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                    if (VIEW == 1) { fy = uzr; fz = uy; }
                     else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                     vi = (int)fx; vj = (int)fy; vk = (int)fz;
                     Qx += dSx; Qy += dSy; Qz += dSz;
@@ -580,10 +581,10 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
             const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
+            const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
             if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
             const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
@@ -752,10 +753,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     auto scaled_texcoord = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
         const float ux = div_mode<DIVTC>(ax + P.half[0], P.ext[0], P.rext[0]);
         const float uy = div_mode<DIVTC>(ay + P.half[1], P.ext[1], P.rext[1]);
-        float uz = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);
-        uz = 1.0f - uz;
+        const float uzr = div_mode<DIVTC>(az + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+        const float uz = 1.0f - uzr;
         float tcx = ux, tcy = uy, tcz = uz;
-        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        if (VIEW == 1) { tcy = uzr; tcz = uy; }
         else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
         fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
     };
@@ -830,9 +831,9 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         for (int u = 0; u < TRI_BATCH; u++) {
             float fx, fy, fz;
             if (POW2) {
-                const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
+                const float ux = Qx + Hx, uy = Qy + Hy, uzr = Qz + Hz, uz = Szv - uzr;
                 fx = ux; fy = uy; fz = uz;
-                if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                if (VIEW == 1) { fy = uzr; fz = uy; }
                 else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                 Qx += dSx; Qy += dSy; Qz += dSz;
             } else {
@@ -884,10 +885,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
     auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
         const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
         const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-        float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-        uz = 1.0f - uz;
+        const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+        const float uz = 1.0f - uzr;
         float tcx = ux, tcy = uy, tcz = uz;
-        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        if (VIEW == 1) { tcy = uzr; tcz = uy; }
         else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
         if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
         uint32_t off[8], tv[8];
@@ -1075,10 +1076,10 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         for (int h = 0; h < head && !head_ended; h++) {
             const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
+            const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
             if (h >= P.max_steps || tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f) head_ended = true;
             x += dsx; y += dsy; z += dsz;
@@ -1134,18 +1135,18 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             for (int u = 0; u < RELAY_BATCH; u++) {
                 int vi, vj, vk;
                 if (POW2) {
-                    const float ux = x + Hx, uy = y + Hy, uz = Szv - (z + Hz);
+                    const float ux = x + Hx, uy = y + Hy, uzr = z + Hz, uz = Szv - uzr;
                     float fx = ux, fy = uy, fz = uz;
-                    if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+                    if (VIEW == 1) { fy = uzr; fz = uy; }
                     else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
                     vi = (int)fx; vj = (int)fy; vk = (int)fz;
                 } else {
                     const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
                     const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-                    float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-                    uz = 1.0f - uz;
+                    const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+                    const float uz = 1.0f - uzr;
                     float tcx = ux, tcy = uy, tcz = uz;
-                    if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                    if (VIEW == 1) { tcy = uzr; tcz = uy; }
                     else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
                     vi = (int)(tcx * P.fdim[0]); vj = (int)(tcy * P.fdim[1]); vk = (int)(tcz * P.fdim[2]);
                 }
@@ -1262,10 +1263,10 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             for (int h = 0; h < head && i < P.max_steps; h++) {
                 const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
                 const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-                float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-                uz = 1.0f - uz;
+                const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+                const float uz = 1.0f - uzr;
                 float tcx = ux, tcy = uy, tcz = uz;
-                if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+                if (VIEW == 1) { tcy = uzr; tcz = uy; }
                 else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
                 if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
                 const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
@@ -1317,10 +1318,10 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         for (; i < P.max_steps; i++) {
             const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
+            const float uzr = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
             if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
             const int vi = min((int)(tcx * P.fdim[0]), nxm1);

@@ -201,26 +201,26 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // few ulp otherwise -- only the load plan uses it, behind its margins
     auto voxel_float = [&](float ax, float ay, float az, float &fx, float &fy, float &fz) {
         const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
-        const float uz = 1.0f - (az + P.half[2]) * P.rext[2];
+        const float uzr = (az + P.half[2]) * P.rext[2], uz = 1.0f - uzr;
         float tcx = ux, tcy = uy, tcz = uz;
-        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        if (VIEW == 1) { tcy = uzr; tcz = uy; }
         else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
         fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
     };
     // scaled texcoord (texcoord * dimension per voxel axis) of the CURRENT position, the shader's operations
     auto scaled_here = [&](float &fx, float &fy, float &fz) {
         if (POW2) {
-            const float ux = Qx + Hx, uy = Qy + Hy, uz = Szv - (Qz + Hz);
+            const float ux = Qx + Hx, uy = Qy + Hy, uzr = Qz + Hz, uz = Szv - uzr;
             fx = ux; fy = uy; fz = uz;
-            if (VIEW == 1) { fy = Szv - uz; fz = uy; }
+            if (VIEW == 1) { fy = uzr; fz = uy; }
             else if (VIEW == 2) { fy = uz; fz = Syv - uy; }
         } else {
             const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
             const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            float uz = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);
-            uz = 1.0f - uz;
+            const float uzr = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
             float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }
             else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
             fx = tcx * P.fdim[0]; fy = tcy * P.fdim[1]; fz = tcz * P.fdim[2];
         }
@@ -289,10 +289,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     auto checked_step = [&](float &x, float &y, float &z, float stx, float sty, float stz) -> bool {
         const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
         const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-        float uz = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);
-        uz = 1.0f - uz;
+        const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+        const float uz = 1.0f - uzr;
         float tcx = ux, tcy = uy, tcz = uz;
-        if (VIEW == 1) { tcy = 1.0f - uz; tcz = uy; }
+        if (VIEW == 1) { tcy = uzr; tcz = uy; }
         else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
         if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) return true;
         uint32_t tv[8];
