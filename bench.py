@@ -95,31 +95,50 @@ def parse_args():
     return ap.parse_args()
 
 
-def self_launch(args) -> int:
+def self_launch(args, run=None) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, RCCL over
-    xGMI) by re-executing this file under torch.distributed.run, forward rank 0's JSON line."""
+    xGMI) by re-executing this file under torch.distributed.run, forward rank 0's JSON line.  If that run fails
+    (first contact with a node's RCCL / rendezvous), retry ONCE through --native-group (one process, the C ABI's
+    vr_group_*: no torch.distributed, its own RCCL communicators) and say in the line which launcher produced it.
+    `run` = subprocess.run (a test hook)."""
     import socket
     import subprocess
 
+    run = run or subprocess.run
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    me = str(Path(__file__).resolve())
+
+    def json_line(proc):
+        line = None
+        for ln in (proc.stdout or "").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            elif ln.strip():
+                print(ln, file=sys.stderr)
+        return line
+
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for ln in proc.stdout.splitlines():
-        if ln.startswith("{") and '"metric"' in ln:
-            line = ln
-        elif ln.strip():
-            print(ln, file=sys.stderr)
-    if proc.returncode != 0 or line is None:
-        print(f"[bench] the {args.gpus}-rank run failed (exit code {proc.returncode})", file=sys.stderr)
-        return proc.returncode or 1
-    print(line, flush=True)
+           "--master-addr", "127.0.0.1", "--master-port", str(port), me] + sys.argv[1:]
+    proc = run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = json_line(proc)
+    if proc.returncode == 0 and line is not None:
+        print(line, flush=True)
+        return 0
+    print(f"[bench] the {args.gpus}-rank torch.distributed.run failed (exit code {proc.returncode}); retrying once through --native-group",
+          file=sys.stderr)
+    proc2 = run([sys.executable, me] + sys.argv[1:] + ["--native-group"], env=env, stdout=subprocess.PIPE, text=True)
+    line = json_line(proc2)
+    if proc2.returncode != 0 or line is None:
+        print(f"[bench] the native-group retry failed too (exit code {proc2.returncode})", file=sys.stderr)
+        return proc2.returncode or proc.returncode or 1
+    rec = json.loads(line)
+    rec.setdefault("config", {})["launcher_fallback"] = f"torch.distributed.run exited with code {proc.returncode}; this line is the native vr_group retry"
+    print(json.dumps(rec), flush=True)
     return 0
 
 
@@ -216,11 +235,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # nccl == RCCL on ROCm.  VR_BENCH_BACKEND=gloo is a validation hook only (several
         # ranks sharing one GPU, gather staged through host memory).
+        from datetime import timedelta
+
         backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
         else:
             dist.init_process_group(backend)
+        # a host-side group next to RCCL: bookkeeping reductions (sample totals, timings, flags) and -- if the RCCL
+        # preflight below fails -- the fallback transport of the shards themselves (through host memory)
+        host_pg = dist.new_group(backend="gloo", timeout=timedelta(seconds=180))
+
+    def host_reduce(values, op="sum", dtype=None):
+        """all-reduce of a few host numbers over the gloo group (never touches RCCL)"""
+        if world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=dtype or torch.float64)
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=host_pg)
+        return t.tolist()
 
     vra = importlib.import_module("volume-renderer_amd")
     from importlib import import_module
@@ -299,14 +331,27 @@ def main():
     my_samples = r.countSamples()
     r.setFramebufferExternal(local.data_ptr())
     r.setFramebufferCompact(True)
-    total_samples = my_samples
-    if world > 1:
-        t = torch.tensor([my_samples], dtype=torch.int64, device=dev)
-        dist.all_reduce(t)
-        total_samples = int(t.item())
+    total_samples = int(host_reduce([my_samples], "sum", torch.int64)[0])
 
     step_no = [0]
     root = 0 if (world > 1 and args.collective == "gather") else None
+    # ---- RCCL preflight (untimed): the exact collective of a step, once, on a zero frame.  Every rank reports over the
+    # host group whether it came back; if any did not, ALL ranks switch the shards to the host-staged gloo transport and
+    # the line says so -- a measured line on a degraded transport beats no line on the node's first RCCL contact.
+    transport = {"name": "RCCL (nccl backend) over xGMI" if world > 1 and dist.get_backend() == "nccl" else ("gloo (validation)" if world > 1 else None),
+                 "group": None, "host_staged": None}
+    if world > 1 and dist.get_backend() == "nccl" and not os.environ.get("VR_BENCH_SKIP_PREFLIGHT"):
+        ok, why = 1, ""
+        try:
+            if os.environ.get("VR_BENCH_FAIL_PREFLIGHT"):
+                raise RuntimeError("VR_BENCH_FAIL_PREFLIGHT (test hook)")
+            sharding.gather_frame(locals_[0], plan, out=gathered[0], index=index, root=root)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:
+            ok, why = 0, repr(exc)[:200]
+        if int(host_reduce([ok], "min", torch.int64)[0]) == 0:
+            transport = {"name": "gloo through host memory (FALLBACK: the RCCL preflight failed" + (f" on rank {rank}: {why}" if why else " on another rank") + ")",
+                         "group": host_pg, "host_staged": True}
 
     def step(ev_pair=None):
         slot = step_no[0] % nslots
@@ -325,14 +370,15 @@ def main():
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev_rendered[slot])
             frame = sharding.gather_frame(locals_[slot], plan, out=gathered[slot], index=index, root=root,
-                                          assembler=r, frame_out=frames[slot])     # one kernel: de-interleave + (grey, alpha) -> RGBA
+                                          assembler=r, frame_out=frames[slot],     # one kernel: de-interleave + (grey, alpha) -> RGBA
+                                          group=transport["group"], host_staged=transport["host_staged"])
             ev_gathered[slot].record(comm_stream)
         return frame
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=transport["group"])
             torch.cuda.synchronize(dev)
 
     frame = None
@@ -351,12 +397,12 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     kernel_ms = sum(a.elapsed_time(c) for a, c in ev) / args.steps
+    elapsed, kernel_ms_max = host_reduce([elapsed, kernel_ms], "max")
+    per_rank_kernel_ms = None
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max = float(t[0].item()), float(t[1].item())
-    else:
-        kernel_ms_max = kernel_ms
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, round(kernel_ms, 4), group=host_pg)
+        per_rank_kernel_ms = per_rank
     ms_per_step = elapsed * 1e3 / args.steps
 
     # untimed self-check of the N > 1 path: the gathered frame must equal this rank's own
@@ -373,12 +419,13 @@ def main():
             gather_ok = bool(np.array_equal(full.view(np.uint32), frame.cpu().numpy().view(np.uint32)))
         sharding.apply_plan(r, plan)
         r.setFramebufferExternal(locals_[0].data_ptr()); r.setFramebufferCompact(True)
-        t = torch.tensor([1 if gather_ok else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        gather_ok = bool(t.item())
-        t = torch.tensor([1], dtype=torch.int64, device=dev)     # ranks counted by the communicator itself
-        dist.all_reduce(t)
-        n_ranks_seen = int(t.item())
+        gather_ok = bool(int(host_reduce([1 if gather_ok else 0], "min", torch.int64)[0]))
+        if transport["group"] is None:
+            t = torch.tensor([1], dtype=torch.int64, device=dev)     # ranks counted by the RCCL communicator itself
+            dist.all_reduce(t)
+            n_ranks_seen = int(t.item())
+        else:
+            n_ranks_seen = int(host_reduce([1], "sum", torch.int64)[0])
 
     result = None
     if rank == 0:
@@ -451,6 +498,9 @@ def main():
         if world > 1:
             result["multi_gpu_frame_bit_exact"] = gather_ok
             result["n_ranks_seen"] = n_ranks_seen
+            result["transport"] = transport["name"]
+            result["per_rank_kernel_ms"] = per_rank_kernel_ms
+            result["config"]["launcher"] = "torch.distributed.run (one process per GPU)"
             result["overlap"] = f"{args.collective} of frame i on a second stream overlaps the kernel of frame i+1"
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
@@ -464,7 +514,7 @@ def main():
         except Exception as exc:                              # evidence only: never costs the headline line
             result["extras"]["baseline_configs_error"] = repr(exc)
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=host_pg)
         dist.destroy_process_group()
     r.close()
     if result is not None:
@@ -823,6 +873,17 @@ def extras(args, r, local, stream, b, W, H):
         torch.cuda.synchronize()
         out["orbiting_camera_wall_ms_per_frame"] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
         r.resetCamera()
+    if b == 2 and not args.no_pack12 and not args.dataset and args.synth == "noise_ball" and not args.window and args.filter == "nearest":
+        # the same volume stored the way CT data is (every voxel + 1000, the reference's own convention,
+        # src/RendererCore.cpp:66-67) under the window 1000 .. 5095: the 12-bit copy packs (voxel - min), so this
+        # must run at the headline's rate, not at headline_without_pack12's (last: it replaces the resident volume)
+        dims = tuple(args.dims) if args.dims else (args.volume,) * 3
+        r.setFramebufferExternal(0); r.setFramebufferCompact(False)
+        r.generateSynthetic(R.SYNTH_NOISE_BALL_CT, dims, 2, 0x9E3779B9)
+        r.setWindow(1000, 5095)
+        vol_host[0] = None
+        timed("headline_offset1000", min_val=1000, max_val=5095)
+        out["headline_offset1000"]["packed_copy_bytes"] = r.pack12Bytes()
     return out
 
 

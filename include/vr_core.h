@@ -39,7 +39,8 @@ enum {
 enum { VR_FILTER_NEAREST = 0, VR_FILTER_TRILINEAR = 1 };
 enum { VR_ACCUM_ITERATIVE = 0, VR_ACCUM_CLOSED_FORM = 1 };
 enum { VR_LAYOUT_LINEAR = 0, VR_LAYOUT_BRICKED = 1 };
-enum { VR_SYNTH_SPHERE_U8 = 0, VR_SYNTH_NOISE_BALL = 1 };
+enum { VR_SYNTH_SPHERE_U8 = 0, VR_SYNTH_NOISE_BALL = 1,
+       VR_SYNTH_NOISE_BALL_CT = 2 /* 16-bit only: the noise ball + 1000, i.e. stored the way the reference expects CT data (src/RendererCore.cpp:66-67) */ };
 
 /* quirk switches (SURVEY.md section 8(a) quirk list); default = VR_QUIRK_DEFAULT */
 enum {
@@ -98,7 +99,7 @@ int vr_read_volume_file(vr_handle h, const char *path, int datasize_bytes);
 int vr_set_volume(vr_handle h, const void *host_voxels, int nx, int ny, int nz,
                   int datasize_bytes, float sx, float sy, float sz);
 /* generate a synthetic volume directly in HBM (never crosses PCIe).
-   kind = VR_SYNTH_SPHERE_U8 (param = radius in voxels) or VR_SYNTH_NOISE_BALL
+   kind = VR_SYNTH_SPHERE_U8 (param = radius in voxels), VR_SYNTH_NOISE_BALL or VR_SYNTH_NOISE_BALL_CT
    (param = seed). */
 int vr_generate_synthetic(vr_handle h, int kind, int nx, int ny, int nz, int datasize_bytes,
                           uint32_t param);

@@ -372,7 +372,7 @@ def test_cfg3_full_size_fast_equals_generic_and_layouts_agree(vra, cfg3):
     assert r.last_kernel_name in FAST_KERNELS
     fast = r.readPixels()
     total = r.countSamples()
-    assert total == 480301374                     # S of BASELINE.md section 2 (4.803e8)
+    assert total == 480301385                     # S of BASELINE.md section 2 (4.803e8)
     r.setKernelVariant(1)
     r.render()
     assert r.last_kernel_name == "raymarch_generic_kernel"
@@ -587,7 +587,7 @@ def test_skip_empty_full_size_windowed(vra, oracle, cfg3):
     r.setSkipEmpty(False)
     r.setWindow(0, 4095)
     assert np.array_equal(plain.view(np.uint32), skipped.view(np.uint32))
-    assert total == 480301374                       # logical samples are unchanged
+    assert total == 480301385                       # logical samples are unchanged
     print(f"cfg3 window [64,4095]: {t_plain:.3f} ms without, {t_skip:.3f} ms with empty-space skipping")
     assert t_skip < t_plain
 
@@ -642,6 +642,59 @@ def test_packed12_copy_is_lossless_and_only_used_when_the_data_allow(vra, oracle
         assert r.pack12Bytes() == 0
     want, _ = oracle.render(vol, oracle.OracleParams(64, 64, alpha_scale=0.3, min_val=0, max_val=65535))
     assert_same(got, want, what="u16 volume with a voxel > 4095")
+
+
+def test_packed12_copy_takes_any_offset_when_the_range_fits_12_bits(vra, oracle):
+    """Round 5: eligibility is max - min <= 4095, not max <= 4095 -- CT data stored with the reference's own +1000
+    convention (src/RendererCore.cpp:66-67) or any other offset packs as (voxel - min).  Clamping windows, windows wider
+    than the data (no clamp), a window too wide for the LDS table (float classification), MIP, a transfer function, the
+    relay kernel, and the +1000 quirk itself: all bit-exact against the oracle and against the unpacked path."""
+    rng = np.random.default_rng(512)
+    R = vra.renderer
+    for dims, base in (((64, 64, 64), 1000), ((37, 21, 50), 61440), ((40, 48, 24), 17)):
+        vol = (rand_volume(rng, dims, np.uint16, smooth=True).astype(np.int64) + base).astype(np.uint16)
+        vol.flat[0] = base; vol.flat[-1] = base + 4095
+        cases = [dict(win=(base + 200, base + 3000)), dict(win=(max(base - 500, 0), min(base + 4500, 65535))),
+                 dict(win=(0, 65535), alpha=0.4), dict(win=(base + 100, base + 3500), mip=1, alpha=0.6),
+                 dict(win=(base, base + 4095), tf=True), dict(win=(base + 200, base + 3000), variant=3)]
+        if base == 1000:
+            cases.append(dict(win=(0, 4095), quirks=R.QUIRK_U16_OFFSET))       # the GUI's window 0 .. 4095 uploaded as 1000 .. 5095
+        for c in cases:
+            frames = {}
+            lo, hi = c["win"]
+            alpha = c.get("alpha", 0.05)
+            for pack in (1, 0):
+                with make_renderer(vra, (96, 80)) as r:
+                    r.setQuirks(c.get("quirks", 0)); r.setLayout(R.LAYOUT_BRICKED); r.setPack12(pack)
+                    r.setKernelVariant(c.get("variant", 0))
+                    r.setVolume(vol); r.setWindow(lo, hi); r.setAlpha(alpha); r.setMIP(bool(c.get("mip", 0)))
+                    tf = None
+                    if c.get("tf"):
+                        r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.3, 0.5, 0.1, 0.759], [0.8, 0.2, 0.4, 0.45], [1, 1, 1, 1]])
+                        tf = r.getTransferLut()
+                    r.cameraOrient(0.0, -0.4, 0.9)
+                    block = r.getCameraBlock()
+                    r.render()
+                    frames[pack] = r.readPixels()
+                    assert (r.pack12Bytes() > 0) == bool(pack), (dims, base, c, pack)
+                    _, spp = r.countSamples(per_pixel=True)
+                    assert r.last_kernel_name in FAST_KERNELS
+            off = 1000 if c.get("quirks", 0) & R.QUIRK_U16_OFFSET else 0
+            p = oracle.OracleParams(96, 80, cam=block, alpha_scale=alpha, min_val=lo + off, max_val=hi + off, is_mip=c.get("mip", 0), tf_rgba=tf)
+            want, _, want_spp = oracle.render(vol, p, want_spp=True)
+            assert_same(frames[1], want, spp, want_spp, what=f"packed12 dims {dims} base {base} {c}")
+            assert np.array_equal(frames[1].view(np.uint32), frames[0].view(np.uint32)), (dims, base, c)
+    # a range of 4097 values does not pack
+    vol = rand_volume(rng, (32, 32, 32), np.uint16)
+    vol = (vol.astype(np.int64) + 300).astype(np.uint16)
+    vol.flat[0] = 300; vol.flat[1] = 300 + 4096
+    with make_renderer(vra, (64, 64)) as r:
+        r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED); r.setVolume(vol); r.setWindow(300, 4396); r.setAlpha(0.3)
+        r.render()
+        got = r.readPixels()
+        assert r.pack12Bytes() == 0
+    want, _ = oracle.render(vol, oracle.OracleParams(64, 64, alpha_scale=0.3, min_val=300, max_val=4396))
+    assert_same(got, want, what="u16 volume spanning 4097 values")
 
 
 def test_long_axis_volume_without_address_tables(vra, oracle):
@@ -933,7 +986,7 @@ def test_short_batches_for_high_opacity(vra, cfg3):
         assert r.last_kernel_name == ("raymarch_generic_kernel" if variant == 1 else "raymarch_fast_kernel")
         frames.append(r.readPixels())
         totals.append(r.countSamples())
-    assert totals[0] == totals[1] == totals[2] == 139601127          # the shallow regime of BASELINE.md
+    assert totals[0] == totals[1] == totals[2] == 139601160          # the shallow regime of BASELINE.md
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
     r.setKernelVariant(0)

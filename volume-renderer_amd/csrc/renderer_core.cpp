@@ -263,8 +263,8 @@ void RendererCore::setVolume(const void *host, int nx, int ny, int nz, int bytes
 
 void RendererCore::generateSynthetic(int kind, int nx, int ny, int nz, int bytes, uint32_t param)
 {
-    if (nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2) || (kind != 0 && kind != 1) ||
-        (kind == 0 && bytes != 1))
+    if (nx <= 0 || ny <= 0 || nz <= 0 || (bytes != 1 && bytes != 2) || (kind != 0 && kind != 1 && kind != 2) ||
+        (kind == 0 && bytes != 1) || (kind == 2 && bytes != 2))
         throw std::invalid_argument("generateSynthetic: bad arguments");
     if ((uint64_t)nx > (1ull << 48) / (uint64_t)ny / (uint64_t)nz / (uint64_t)bytes)
         throw std::invalid_argument("generateSynthetic: volume too large");
@@ -278,7 +278,7 @@ void RendererCore::generateSynthetic(int kind, int nx, int ny, int nz, int bytes
     tex3D_dim[0] = nx; tex3D_dim[1] = ny; tex3D_dim[2] = nz;
     voxel_size[0] = voxel_size[1] = voxel_size[2] = 1.0f;
     datasize_bytes = bytes;
-    afterVolumeLoaded(kind == 0 ? "<synthetic sphere>" : "<synthetic noise ball>");
+    afterVolumeLoaded(kind == 0 ? "<synthetic sphere>" : (kind == 1 ? "<synthetic noise ball>" : "<synthetic noise ball + 1000>"));
 }
 
 void RendererCore::readVolume(void *host, size_t bytes)
@@ -877,16 +877,19 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
     last_choice_ = c;
 }
 
-// 12-bit packed copy (vr_set_pack12, default on): when every voxel of a bricked u16 volume is
-// <= 4095 (12-bit CT data, BASELINE's synthetic volume) the fast kernel's prefix gathers from a
-// lossless copy with 1.5 bytes per voxel -- the launch is bound by the number of cache lines
-// it moves, and this is 25 % fewer.  The u16 volume stays resident for
-// every other kernel and for the checked tail of each ray.
-void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
+// 12-bit packed copy (vr_set_pack12, default on): when the voxels of a bricked u16 volume span at most 4096
+// values (max - min <= 4095: 12-bit CT data whatever its offset -- the reference's own +1000 convention,
+// src/RendererCore.cpp:66-67, stores 1000 .. 5095 -- and BASELINE's synthetic volume) the fast kernel's prefix
+// gathers from a lossless copy of (voxel - min) with 1.5 bytes per voxel: the launch is bound by the number of
+// cache lines it moves, and this is 25 % fewer.  The minimum is folded into the window limits and
+// the table bias the kernel already carries (FrameParams::pk12_base), so the sample loop is the same code.  The
+// u16 volume stays resident for every other kernel and for the checked head / tail of each ray.
+void RendererCore::refreshPacked12(FrameParams &P, LaunchConfig &L)
 {
     L.packed12 = nullptr;
     L.packed12_bytes = 0;
-    if (!pack12 || res_bytes_ != 2 || vol_layout_ != 1 || L.big_offsets || exact_max_ > 4095) return;
+    P.pk12_base = 0;
+    if (!pack12 || res_bytes_ != 2 || vol_layout_ != 1 || L.big_offsets || exact_max_ - exact_min_ > 4095) return;
     if (!fast_path_eligible(P, L)) return;
     const size_t voxels = storageVoxels(res_dims_[0], res_dims_[1], res_dims_[2], 1);
     const size_t bytes = voxels / 2 * 3;
@@ -899,7 +902,8 @@ void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
             vol12_failed_ = true;
             return;
         }
-        hipError_t e = launch_pack12(d_vol_, d_vol12_, voxels, stream());
+        hipError_t e = launch_pack12(d_vol_, d_vol12_, voxels, (uint32_t)exact_min_, stream());
+        vol12_base_ = exact_min_;
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         if (e != hipSuccess) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; }
         check(e, "pack12_kernel");
@@ -907,6 +911,7 @@ void RendererCore::refreshPacked12(const FrameParams &P, LaunchConfig &L)
     }
     L.packed12 = d_vol12_;
     L.packed12_bytes = (uint32_t)vol12_bytes_;
+    P.pk12_base = vol12_base_;
 }
 
 // TRILINEAR's apron copy (vr_set_trilinear_copy, default on; vr_device.h: build_axis_tables_apron): the bricked

@@ -162,7 +162,8 @@ private:
     size_t vol12_bytes_ = 0;
     bool vol12_failed_ = false;              // allocation of the packed copy failed for this volume: do not retry
     size_t last_packed12_bytes_ = 0;         // packed copy used by the last launch (0 = none)
-    void refreshPacked12(const FrameParams &P, LaunchConfig &L);
+    int vol12_base_ = 0;                     // the packed copy holds voxel - vol12_base_ (the dataset minimum when it was built)
+    void refreshPacked12(FrameParams &P, LaunchConfig &L);
     void *d_apron_ = nullptr;                // TRILINEAR's apron copy of the volume (vr_frame.h: apron_voxels)
     void *d_apron_perm_[2] = {nullptr, nullptr};   // the same with the bricks' planes along y / x slowest (half layers of the staged kernel; 16-bit volumes, oblique views)
     bool apron_perm_failed_ = false;

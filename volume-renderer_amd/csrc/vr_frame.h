@@ -61,6 +61,7 @@ struct FrameParams {
     // bricked layout (VR_LAYOUT_BRICKED): bricks of 4x4x4 voxels, x-fastest inside
     int32_t bnx, bny, bnz;         // bricks per axis
     uint32_t bstride_y, bstride_z; // brick-row / brick-slab strides minus the in-brick part (see VoxelAddr)
+    int32_t pk12_base;             // the 12-bit packed copy holds voxel - pk12_base (the dataset minimum); 0 without a packed copy
 };
 
 struct LaunchConfig {

@@ -45,7 +45,7 @@ hipError_t launch_stats(const void *vol, int bytes_per_voxel, uint32_t nx, uint3
                         hipStream_t st);
 
 // 12-bit packed copy (voxels a multiple of 8, every voxel <= 4095): 1.5 bytes per voxel
-hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStream_t st);
+hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, uint32_t base, hipStream_t st);
 
 // RGBA32F -> RGBA8 with glReadPixels' conversion rule
 hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pixels, hipStream_t st);

@@ -372,7 +372,13 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         };
         constexpr int LUT_SHIFT = 3;
         // byte offset of entry 0 relative to texel*entry_bytes (MODE 2: of index byte 0 relative to texel)
-        const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
+        // PK12: the packed copy stores voxel - pk12_base (the dataset minimum), so a volume whose RANGE fits 12 bits
+        // packs, whatever its offset (CT data stored 1000 .. 5095).  classify() then works on the packed values: the
+        // window limits and the table bias are shifted by the base instead of the texel -- no instruction is added to
+        // the sample loop; the rare checked steps subtract the base from the u16 voxel they read.
+        const int pkb = PK12 ? P.pk12_base : 0;
+        const int wmin = P.min_val - pkb, wmax = P.max_val - pkb;
+        const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - wmin : -8 * wmin;
         uint32_t lut_entry0 = lds_offset_of(lut) + (uint32_t)lut_bias;
         asm volatile("" : "+v"(lut_entry0));
         // window + classification of one texel -> premultiplied colour c (cg, cb only in MODE 2)
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
             if (LUT) {
                 int t = (int)texel;
-                if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);   // clamp(texel, min_val, max_val), min <= max
+                if (!NOCLAMP) t = med3_i32(t, wmin, wmax);   // clamp(texel, min_val, max_val), min <= max
                 if (MODE >= 2) {
                     const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[(uint32_t)(t + lut_bias)];
                     const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     c = ca[0]; a = ca[1];
                 }
             } else {
-                float s = (float)texel;
+                float s = (float)(texel + (uint32_t)pkb);
                 s = fminf(fmaxf(s, P.fmin), P.fmax);        // operands are never NaN here
                 s = div_cert(s - P.fmin, P.fden, P.rden);
                 a = s * P.alpha_scale;
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
             const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
             float c, cg = 0.0f, cb = 0.0f, a;
-            classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)), c, cg, cb, a);
+            classify(VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk)) - (uint32_t)pkb, c, cg, cb, a);
             accumulate(c, cg, cb, a);
             x += stx; y += sty; z += stz;
             return false;
@@ -1100,7 +1106,9 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     // cycles instead of 2.3 -- fp32 and integer alike, tools/ubench/valu_rates2.hip)
     float Szv = Sz, Syv = Sy;
     asm volatile("" : "+v"(Szv), "+v"(Syv));
-    const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - P.min_val : -8 * P.min_val;
+    const int pkb = PK12 ? P.pk12_base : 0;      // see the fast kernel: classify() works on packed values (voxel - base)
+    const int wmin = P.min_val - pkb, wmax = P.max_val - pkb;
+    const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - wmin : -8 * wmin;
 
     // The ray positions travel the same way as the compositing state: the wavefront that
     // generated the addresses of batch n publishes the position at the start of batch n+1
@@ -1174,7 +1182,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     auto classify = [&](uint32_t texel, float &c, float &cg, float &cb, float &a) {
         if (LUT) {
             int t = (int)texel;
-            if (!NOCLAMP) t = med3_i32(t, P.min_val, P.max_val);
+            if (!NOCLAMP) t = med3_i32(t, wmin, wmax);
             if (MODE >= 2) {
                 const uint32_t idx = reinterpret_cast<const uint8_t *>(lut)[(uint32_t)(t + lut_bias)];
                 const float4 q = reinterpret_cast<const float4 *>(lut)[idx];
@@ -1184,7 +1192,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             const float2 ca = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(lut) + (uint32_t)((t << 3) + lut_bias));
             c = ca.x; a = ca.y;
         } else {
-            float s = (float)texel;
+            float s = (float)(texel + (uint32_t)pkb);
             s = fminf(fmaxf(s, P.fmin), P.fmax);
             s = div_cert(s - P.fmin, P.fden, P.rden);
             a = s * P.alpha_scale;
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
                 const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
                 const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
                 float c, cg = 0.0f, cb = 0.0f, a;
-                classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, cg, cb, a);
+                classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)) - (uint32_t)pkb, c, cg, cb, a);
                 accumulate(drgb, dg, db, da, c, cg, cb, a);
                 x += dsx; y += dsy; z += dsz;
                 i++;
@@ -1328,7 +1336,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
             const int vj = min((int)(tcy * P.fdim[1]), nym1);
             const int vk = min((int)(tcz * P.fdim[2]), nzm1);
             float c, cg = 0.0f, cb = 0.0f, a;
-            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)), c, cg, cb, a);
+            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)) - (uint32_t)pkb, c, cg, cb, a);
             accumulate(drgb, dg, db, da, c, cg, cb, a);
             qx += tsx; qy += tsy; qz += tsz;
         }
@@ -1391,6 +1399,7 @@ __global__ __launch_bounds__(256) void gen_volume_kernel(VoxelT *__restrict__ ou
             const uint32_t h = fmix32(((uint32_t)lin ^ (uint32_t)(lin >> 32) * 0x9E3779B1u) ^ param) & 0xFFu;
             v = base + (int64_t)(h >> shift);
             if (v > vmax) v = vmax;
+            if (kind == 2) v += 1000;   // VR_SYNTH_NOISE_BALL_CT (16-bit): the same ball stored as CT data is, offset by +1000
         }
         out[storage_index(layout, i, j, k, nx, ny, bnx, bny)] = (VoxelT)v;
     }
@@ -1923,13 +1932,16 @@ hipError_t launch_relayout_apron(const void *vol, void *out, int bytes_per_voxel
 }
 
 // storage order works; the fast kernel reads the bricked one (PK12).
-__global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ dst, uint64_t ngroups)
+__global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ src, uint32_t *__restrict__ dst, uint64_t ngroups, uint32_t base)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
         const uint4 q = src[g];
-        const uint32_t v0 = q.x & 0xfffu, v1 = (q.x >> 16) & 0xfffu, v2 = q.y & 0xfffu, v3 = (q.y >> 16) & 0xfffu;
-        const uint32_t v4 = q.z & 0xfffu, v5 = (q.z >> 16) & 0xfffu, v6 = q.w & 0xfffu, v7 = (q.w >> 16) & 0xfffu;
+        // voxel - base: the caller guarantees base <= voxel <= base + 4095 for every voxel of the volume
+        const uint32_t v0 = ((q.x & 0xffffu) - base) & 0xfffu, v1 = ((q.x >> 16) - base) & 0xfffu, v2 = ((q.y & 0xffffu) - base) & 0xfffu,
+                       v3 = ((q.y >> 16) - base) & 0xfffu;
+        const uint32_t v4 = ((q.z & 0xffffu) - base) & 0xfffu, v5 = ((q.z >> 16) - base) & 0xfffu, v6 = ((q.w & 0xffffu) - base) & 0xfffu,
+                       v7 = ((q.w >> 16) - base) & 0xfffu;
         dst[3 * g + 0] = v0 | (v1 << 12) | (v2 << 24);
         dst[3 * g + 1] = (v2 >> 8) | (v3 << 4) | (v4 << 16) | (v5 << 28);
         dst[3 * g + 2] = (v5 >> 4) | (v6 << 8) | (v7 << 20);
@@ -1937,9 +1949,9 @@ __global__ __launch_bounds__(256) void pack12_kernel(const uint4 *__restrict__ s
 }
 
 
-hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, hipStream_t st)
+hipError_t launch_pack12(const void *src_u16, void *dst, uint64_t voxels, uint32_t base, hipStream_t st)
 {
-    hipLaunchKernelGGL(pack12_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src_u16, (uint32_t *)dst, voxels / 8u);
+    hipLaunchKernelGGL(pack12_kernel, dim3(256 * 16), dim3(256), 0, st, (const uint4 *)src_u16, (uint32_t *)dst, voxels / 8u, base);
     return hipGetLastError();
 }
 

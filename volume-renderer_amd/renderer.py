@@ -27,7 +27,7 @@ FILTER_NEAREST, FILTER_TRILINEAR = 0, 1
 ACCUM_ITERATIVE, ACCUM_CLOSED_FORM = 0, 1
 LAYOUT_LINEAR, LAYOUT_BRICKED = 0, 1
 FB_RGBA32F, FB_GREYALPHA32F = 0, 1     # vr_set_framebuffer_format
-SYNTH_SPHERE_U8, SYNTH_NOISE_BALL = 0, 1
+SYNTH_SPHERE_U8, SYNTH_NOISE_BALL, SYNTH_NOISE_BALL_CT = 0, 1, 2
 QUIRK_TRUNC_GRID, QUIRK_U16_OFFSET = 1, 2
 QUIRK_DEFAULT = QUIRK_U16_OFFSET
 

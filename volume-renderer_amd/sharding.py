@@ -97,7 +97,7 @@ def expand_grey_alpha(ga):
     return ga.index_select(-1, sel)
 
 
-def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assembler=None, frame_out=None):
+def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assembler=None, frame_out=None, group=None, host_staged=None):
     """gather the compact shards and return the assembled [H, W, 4] frame.
 
     root = None: all_gather -- every rank ends up with the frame.  root = k: a GATHER to rank k (RCCL
@@ -112,6 +112,10 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
     assembler = a RendererCore on the same device + frame_out = a preallocated [H, W, 4] float32 tensor: the
     de-interleave and the (grey, alpha) expansion are done by ONE kernel of the C ABI (vr_assemble_shards) on the
     current torch stream instead of two index_select launches.
+
+    group = the process group of the collective (None = the default group).  host_staged = True moves the shards
+    through host memory (device -> host, the collective on CPU tensors, host -> device): what a gloo group needs,
+    and bench.py's fallback transport when the RCCL preflight fails; None = decide from the group's backend.
     """
     import torch
     import torch.distributed as dist
@@ -125,7 +129,7 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
         out = torch.empty((plan.world * plan.local_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     if root is not None:
         is_root = plan.rank == root
-        staged = local.is_cuda and dist.get_backend() == "gloo"      # validation hook: ranks sharing one GPU gather through host memory
+        staged = local.is_cuda and (dist.get_backend(group) == "gloo" if host_staged is None else bool(host_staged))   # gloo: through host memory
         if is_root:
             dst = torch.empty(out.shape, dtype=out.dtype) if staged else out
             # the per-rank views of a CALLER-OWNED gather buffer are built once, not per frame (a buffer allocated
@@ -139,19 +143,19 @@ def gather_frame(local, plan: RowPlan, out=None, index=None, root=None, assemble
                     if len(_GATHER_VIEWS) > 16:
                         _GATHER_VIEWS.clear()
                     _GATHER_VIEWS[key] = pieces
-            dist.gather(local.cpu() if staged else local, gather_list=pieces, dst=root)
+            dist.gather(local.cpu() if staged else local, gather_list=pieces, dst=root, group=group)
             if staged:
                 out.copy_(dst)
         else:
-            dist.gather(local.cpu() if staged else local, dst=root)
+            dist.gather(local.cpu() if staged else local, dst=root, group=group)
             return None
-    elif local.is_cuda and dist.get_backend() == "gloo":
-        # validation hook (several ranks sharing one GPU): stage the gather through host memory
+    elif local.is_cuda and (dist.get_backend(group) == "gloo" if host_staged is None else bool(host_staged)):
+        # gloo (validation: several ranks sharing one GPU; bench.py's fallback transport): through host memory
         host = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(host, local.cpu())
+        dist.all_gather_into_tensor(host, local.cpu(), group=group)
         out.copy_(host)
     else:
-        dist.all_gather_into_tensor(out, local)
+        dist.all_gather_into_tensor(out, local, group=group)
     if assembler is not None and frame_out is not None and out.is_cuda:
         assembler.assembleShards(out.data_ptr(), frame_out.data_ptr(), plan.world, plan.local_rows,
                                  0 if plan.mode == "contiguous" else plan.stripe_rows, local.shape[-1],
