@@ -179,7 +179,8 @@ int vr_set_kernel_variant(vr_handle h, int variant);
 int vr_set_autotune(vr_handle h, int enable);
 /* what the last launch ran as (for tests and tools; no reference equivalent): bit 0 relay kernel, bit 1 pipelined batch loop,
    bit 2 four-sample batches, bits 3..6 the LDS-staged trilinear kernel's shape (0 = not that kernel; the numbers of
-   vr_set_kernel_variant 6 .. 10 minus 5) */
+   vr_set_kernel_variant 6 .. 10 minus 5), bit 8 (256): the measured choice is still EXPLORING this configuration -- the
+   frame was a trial of one candidate (up to ~45 % slower than the settled choice), not the settled kernel */
 int vr_get_launch_choice(vr_handle h);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %
@@ -194,6 +195,18 @@ int vr_get_pack12_bytes(vr_handle h, size_t *bytes);
 int vr_set_trilinear_copy(vr_handle h, int enable);
 /* bytes of the apron copy the last vr_render* gathered from (0: none) */
 int vr_get_trilinear_copy_bytes(vr_handle h, size_t *bytes);
+/* Device memory this handle holds right now (any pointer may be NULL): the volume as loaded (what the reference keeps
+   in its 3-D texture, src/RendererCore.cpp:419); the optional speed copies built beside it (12-bit packed copy, apron
+   copies: up to 0.75 + 3 x 1.25 volumes for a 16-bit volume viewed obliquely with TRILINEAR); everything else (targets,
+   tables, skip grid, staging).  No reference equivalent (the GL driver owns the reference's memory). */
+int vr_get_resident_bytes(vr_handle h, uint64_t *volume, uint64_t *copies, uint64_t *other);
+/* Upper bound, in bytes, on the optional copies together.  VR_COPY_BUDGET_AUTO (default): a copy is built only while the
+   device keeps max(1 GiB, a tenth of its memory) free after it, so that mandatory allocations that come later (skip grid,
+   targets, a group's frame slots) still succeed.  0 = no copies at all.  Lowering the budget frees copies that no longer
+   fit (per-axis aprons first, then the apron, then the packed copy); frames are bit-identical with or without any copy. */
+#define VR_COPY_BUDGET_AUTO UINT64_MAX
+int vr_set_copy_budget(vr_handle h, uint64_t bytes);
+int vr_get_copy_budget(vr_handle h, uint64_t *bytes);
 /* 1-D transfer function (N3): n knots of (iso in 0..255, r,g,b,a); n = 0 restores the
    reference grey ramp.  Built with the natural cubic spline of src/CubicSpline.cpp. */
 int vr_set_transfer_function(vr_handle h, const int32_t *iso, const float *rgba4, int n);

@@ -34,6 +34,18 @@ def test_no_cpu_fallback_gpu_operations_fail_loudly(vra):
     r.close()
 
 
+def test_copy_budget_and_resident_bytes_on_a_host_only_handle(vra):
+    """vr_set_copy_budget / vr_get_resident_bytes (round 5): defaults and round trip; nothing is resident without a device"""
+    r = vra.RendererCore(-1)
+    assert r.copyBudget() == r.COPY_BUDGET_AUTO
+    r.setCopyBudget(3 << 30)
+    assert r.copyBudget() == 3 << 30
+    r.setCopyBudget(r.COPY_BUDGET_AUTO)
+    assert r.copyBudget() == r.COPY_BUDGET_AUTO
+    assert r.residentBytes() == (0, 0, 0)
+    r.close()
+
+
 def test_create_on_missing_device_reports_no_device(vra):
     import torch
 

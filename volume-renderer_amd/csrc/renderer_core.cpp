@@ -162,6 +162,8 @@ bool RendererCore::loadShader(std::string fn, bool reload)
         requireDevice("loadShader");
         check(launch_warm_modules(stream()), "module pre-load");
         check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        tslab_warm_ = false;
+        if (filter == 1) warmTrilinear();
     }
     u_.alpha_scale = alpha_scale;
     if (!loaded_dataset.empty()) {
@@ -677,6 +679,7 @@ float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
     if (!fb) throw std::runtime_error("render: setup() has not allocated the framebuffer");
     if (fb_format_ == 1 && ext_fb_ && !tf_lut_.empty())
         throw std::invalid_argument("render: the (grey, alpha) target format needs a grey mode (no transfer function)");
+    if (filter == 1) warmTrilinear();          // (a caller that set the public field directly; a no-op once done)
     buildFrame(P, L);
     refreshSkipGrid(P, L);
     refreshTileSchedule(P, L);
@@ -688,6 +691,18 @@ float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
     last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
     tuneChoose(P, L);
     return fb;
+}
+
+// the LDS-staged TRILINEAR kernel's seven code objects (vr_tslab.hip), loaded when TRILINEAR is selected -- vr_set_filter,
+// or vr_load_shader with the filter already set -- not by the first frame that needs one of them (round-4 advisor: the
+// measured choice tries several shapes mid-interaction, each of which would pay a lazy decompress + load)
+void RendererCore::warmTrilinear()
+{
+    if (device_ < 0 || tslab_warm_ || !cs_program_) return;
+    requireDevice("warmTrilinear");
+    check(launch_warm_tslab(stream()), "module pre-load (trilinear)");
+    check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    tslab_warm_ = true;
 }
 
 void RendererCore::launch(uint32_t *spp)
@@ -702,8 +717,9 @@ void RendererCore::launch(uint32_t *spp)
     check(launch_raymarch(P, L, d_vol_, d_tf_, fb, spp, stream(), &last_kernel_), "raymarch launch");
     if (measure) {
         check(hipEventRecord(slot.ev1, stream()), "hipEventRecord");
-        slot.key = tune_key_; slot.cand = tune_cand_;
+        slot.key = tune_key_; slot.cand = tune_cand_; slot.gen = tune_gen_;
         tune_count_++;
+        tuneIssued(tune_key_, tune_gen_, tune_cand_);                   // counted only now that its events are on the stream
     }
     tune_measure_ = false;
 }
@@ -720,10 +736,23 @@ static constexpr double kTriWholeLayerAlignment = 0.985;
 // first frames of a configuration try them in turn (the heuristic's choice first), a few times each, and the fastest
 // is kept.  Keyed by everything that shapes the launch; the pose enters through the view's axis alignment and the
 // number of active tiles (buckets), so an orbiting camera re-uses what it has learnt.
-void RendererCore::tuneRecord(uint64_t key, int cand, float ms)
+void RendererCore::tuneIssued(uint64_t key, uint64_t gen, int cand_value)
 {
     auto it = tune_.find(key);
-    if (it == tune_.end() || cand < 0 || cand >= it->second.ncand) return;
+    if (it == tune_.end() || it->second.gen != gen) return;
+    for (int c = 0; c < it->second.ncand; c++) if (it->second.cand[c] == cand_value) { it->second.issued[c]++; return; }
+}
+
+// `cand_value` is the candidate's bit set, `gen` the entry's generation when the measurement was launched: an entry that was
+// evicted and re-created for the same key has another shuffled order (an index would credit the wrong candidate), and a
+// result launched before a re-validation must not count towards it (round-4 advisor)
+void RendererCore::tuneRecord(uint64_t key, uint64_t gen, int cand_value, float ms)
+{
+    auto it = tune_.find(key);
+    if (it == tune_.end() || it->second.gen != gen) return;
+    int cand = -1;
+    for (int c = 0; c < it->second.ncand; c++) if (it->second.cand[c] == cand_value) cand = c;
+    if (cand < 0) return;
     TuneEntry &e = it->second;
     e.best_ms[cand] = e.tries[cand] == 0 ? ms : std::min(e.best_ms[cand], ms);
     e.tries[cand]++;
@@ -751,7 +780,7 @@ void RendererCore::tuneCollect()
         tune_count_--;
         if (q != hipSuccess) { (void)hipGetLastError(); continue; }
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) tuneRecord(s.key, s.cand, ms);
+        if (hipEventElapsedTime(&ms, s.ev0, s.ev1) == hipSuccess) tuneRecord(s.key, s.gen, s.cand, ms);
         else (void)hipGetLastError();
     }
 }
@@ -824,6 +853,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         it = tune_.emplace(key, TuneEntry{}).first;
         TuneEntry &e = it->second;
         e.ncand = n;
+        e.gen = ++tune_gen_counter_;
         for (int k = 0; k < n; k++) e.cand[k] = cand[k];
         e.heur = cand[0];
         // shuffled measuring order (Fisher-Yates on a counter-seeded LCG)
@@ -844,6 +874,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
             for (int c = 0; c < e.ncand; c++) { e.tries[c] = 0; e.issued[c] = 0; e.best_ms[c] = 0.0f; }
             e.settled = -1;
             e.next = 0;
+            e.gen = ++tune_gen_counter_;                                 // results still in flight belong to the old generation
         }
     } else {
         // the next candidate that still needs a measurement launched; when every measurement is in flight (a burst of
@@ -856,9 +887,10 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
             }
         if (pick >= 0) {
             use = pick;
-            e.issued[pick]++;
             e.next = (pick + 1) % e.ncand;
-            tune_measure_ = true; tune_key_ = key; tune_cand_ = use;
+            // issued[] is counted where the event pair is really recorded (launch / render): a launch that cannot measure
+            // (the instrumented sample count, every slot taken) leaves the candidate to be picked again
+            tune_measure_ = true; tune_key_ = key; tune_cand_ = e.cand[use]; tune_gen_ = e.gen;
         } else {
             int best = -1;
             for (int c = 0; c < e.ncand; c++)
@@ -874,7 +906,7 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
     }
     const int c = e.cand[use];
     L.sparse_shard = (c & 1) ? 1 : 0; L.pipelined = (c & 2) ? 1 : 0; L.short_batches = (c & 4) ? 1 : 0; L.tri_slab = (c >> 3) & 15;
-    last_choice_ = c;
+    last_choice_ = c | (e.settled < 0 ? 256 : 0);                        // bit 8: a trial frame of a configuration still being explored
 }
 
 // 12-bit packed copy (vr_set_pack12, default on): when the voxels of a bricked u16 volume span at most 4096
@@ -895,7 +927,7 @@ void RendererCore::refreshPacked12(FrameParams &P, LaunchConfig &L)
     const size_t bytes = voxels / 2 * 3;
     if (bytes + 16 >= (1ull << 32)) return;
     if (!d_vol12_) {
-        if (vol12_failed_) return;
+        if (vol12_failed_ || !copyFits(bytes + 16)) return;
         if (hipMalloc(&d_vol12_, bytes + 16) != hipSuccess) {     // an optimisation only: render from the volume as loaded
             (void)hipGetLastError();
             d_vol12_ = nullptr;
@@ -928,6 +960,7 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     const uint64_t bytes = apron_voxels(res_dims_[0], res_dims_[1], res_dims_[2]) * (uint64_t)res_bytes_;
     if (bytes + 16 >= (1ull << 32) && !tri_slab_candidate(P, L)) return;   // the batched kernel gathers through a 32-bit buffer descriptor
     if (!d_apron_) {
+        if (!copyFits(bytes + 16)) return;                             // over the budget / too little device memory left: not an error
         if (hipMalloc(&d_apron_, bytes + 16) != hipSuccess) {         // an optimisation only
             (void)hipGetLastError();
             d_apron_ = nullptr;
@@ -949,9 +982,14 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     // Half layers of the staged kernel (vr_tslab.hip, 16-bit volumes): two more copies with the bricks' planes along y / x
     // slowest, so that half a brick along any major axis is 80 contiguous bytes.  Built the first time a view is oblique
     // to the volume axes (or kernel variants 8 / 9 ask for them); +2 x 1.25 volumes of HBM.
+    // Only when a launch can use them (round-4 advisor): the staged kernel must be able to run (it walks the tile table),
+    // and either a half-layer shape is forced (variants 8 / 9) or the automatic choice may pick one -- the heuristic's first
+    // guess for an oblique view, or a candidate of the measured choice.  Both or none: a lone copy is freed again.
     const bool oblique = viewAxisAlignment(P) < kTriWholeLayerAlignment;
-    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && ((force_generic >= 8 && force_generic <= 9) || (force_generic == 0 && oblique));
-    if (want_perm && !apron_perm_failed_) {
+    const bool half_layers_possible = (force_generic >= 8 && force_generic <= 9) || (force_generic == 0 && oblique && (L.tri_slab >= 3 || autotune));
+    const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && L.tile_table != nullptr && half_layers_possible;
+    if (want_perm && !apron_perm_failed_ && !(d_apron_perm_[0] && d_apron_perm_[1])) {
+        if (!copyFits(2 * (bytes + 16))) apron_perm_failed_ = true;     // (re-armed by vr_set_copy_budget and by the next volume)
         for (int o = 0; o < 2 && !apron_perm_failed_; o++) {
             if (d_apron_perm_[o]) continue;
             if (hipMalloc(&d_apron_perm_[o], bytes + 16) != hipSuccess) {
@@ -968,12 +1006,54 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
             if (e != hipSuccess) { (void)hipFree(d_apron_perm_[o]); d_apron_perm_[o] = nullptr; }
             check(e, "relayout_apron_kernel");
         }
+        if (apron_perm_failed_)                                         // one without the other is 1.25 volumes of dead memory, in the low-memory case
+            for (void *&q : d_apron_perm_) if (q) { (void)hipFree(q); q = nullptr; }
     }
     if (d_apron_perm_[0] && d_apron_perm_[1]) {
         L.apron_y = d_apron_perm_[0];
         L.apron_x = d_apron_perm_[1];
         last_apron_bytes_ += 2 * apron_bytes_;
     }
+}
+
+uint64_t RendererCore::copiesBytes() const
+{
+    uint64_t b = d_vol12_ ? (uint64_t)vol12_bytes_ + 16 : 0;
+    if (d_apron_) b += (uint64_t)apron_bytes_ + 16;
+    for (void *q : d_apron_perm_) if (q) b += (uint64_t)apron_bytes_ + 16;
+    return b;
+}
+
+bool RendererCore::copyFits(uint64_t bytes) const
+{
+    if (copy_budget_ != kCopyBudgetAuto) return copiesBytes() + bytes <= copy_budget_;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+    const uint64_t reserve = std::max<uint64_t>(kCopyReserveBytes, (uint64_t)total_b / 10);
+    return (uint64_t)free_b >= bytes + reserve;       // mandatory allocations (skip grid, targets, group slots) keep room
+}
+
+void RendererCore::setCopyBudget(uint64_t bytes)
+{
+    copy_budget_ = bytes;
+    vol12_failed_ = apron_failed_ = apron_perm_failed_ = false;          // a new budget re-arms what an old one refused
+    if (device_ < 0 || bytes == kCopyBudgetAuto) return;
+    requireDevice("setCopyBudget");
+    // over the new budget: drop copies, the least valuable first (per-axis aprons, apron, packed copy)
+    if (copiesBytes() > bytes) check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+    if (copiesBytes() > bytes) for (void *&q : d_apron_perm_) if (q) { (void)hipFree(q); q = nullptr; }
+    if (copiesBytes() > bytes && d_apron_) { (void)hipFree(d_apron_); d_apron_ = nullptr; apron_bytes_ = 0; }
+    if (copiesBytes() > bytes && d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
+}
+
+void RendererCore::residentBytes(uint64_t &volume, uint64_t &copies, uint64_t &other) const
+{
+    volume = (uint64_t)vol_alloc_bytes_;
+    copies = copiesBytes();
+    const uint64_t px = (uint64_t)framebuffer_size[0] * (uint64_t)framebuffer_size[1];
+    other = (d_fb_ ? px * 16 : 0) + (d_tf_ ? 256 * 16 : 0) + (uint64_t)spp_capacity_ * 4 + (d_scratch_ ? 264 * 4 : 0) +
+            (d_skip_grid_ ? (uint64_t)skip_grid_cells_ * 2 : 0) + (uint64_t)rgba8_capacity_ + (uint64_t)present_capacity_ * kPresentSlots +
+            ((uint64_t)tile_table_capacity_ + (uint64_t)tile_table_tall_capacity_) * 4;
 }
 
 // Exact empty-space skipping (vr_set_skip_empty): the fast kernel may skip a batch of
@@ -1056,7 +1136,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     const uint64_t shape_key = tileScheduleKey(P, rows, false);
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
-    const bool need32 = filter == 1 && tri_slab_candidate(P, L);   // 16x32-pixel tiles for the staged trilinear kernel's tall shape
+    const bool need32 = filter == 1 && tri_slab_candidate(P, L) && (P.stripe_count <= 1 || P.stripe_rows % 32 == 0 || force_generic == 9);   // 16x32-pixel tiles for the staged trilinear kernel's tall shape
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0)) {
         std::vector<uint32_t> table;
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
@@ -1105,7 +1185,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
         } else {
             double r1, r2;
             viewAxisRatios(P, r1, r2);
-            L.tri_slab = (r1 > 0.7 && r2 > 0.55) ? 4 : 3;
+            // 16x32-pixel tiles only where 32 consecutive LOCAL rows are 32 consecutive image rows: with cyclic stripes of 16
+            // rows a tall tile spans two stripes stripe_count*16 rows apart, its corner-ray hull (and its load plan) is that
+            // much taller, and nearly every tile would march unstaged (round-4 advisor)
+            const bool tall_ok = P.stripe_count <= 1 || P.stripe_rows % 32 == 0;
+            L.tri_slab = (r1 > 0.7 && r2 > 0.55 && tall_ok) ? 4 : 3;
         }
     }
     // first guess of the work model (kernel variant 0 then measures, tuneChoose): the relay kernel pays when the launch is
@@ -1130,7 +1214,7 @@ void RendererCore::render()
     LaunchConfig L;
     float4 *fb = prepareLaunch(P, L);
     const bool measure = tune_measure_;
-    const uint64_t mkey = tune_key_;
+    const uint64_t mkey = tune_key_, mgen = tune_gen_;
     const int mcand = tune_cand_;
     tune_measure_ = false;
     check(hipEventRecord(ev0_, stream()), "hipEventRecord");
@@ -1140,7 +1224,7 @@ void RendererCore::render()
     float ms = 0.0f;
     check(hipEventElapsedTime(&ms, ev0_, ev1_), "hipEventElapsedTime");
     kerneltime_sum += ms;
-    if (measure) tuneRecord(mkey, mcand, ms);                            // the blocking path measures anyway
+    if (measure) { tuneIssued(mkey, mgen, mcand); tuneRecord(mkey, mgen, mcand, ms); }   // the blocking path measures anyway
 }
 
 void RendererCore::renderAsync()

@@ -98,10 +98,19 @@ public:
     double measureStreamRead(int reps);
     void assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream);
     const char *lastKernelName() const { return last_kernel_; }
-    int lastLaunchChoice() const { return last_choice_; }     // 1 relay, 2 pipelined loop, 4 short batches, tri_slab << 3
+    int lastLaunchChoice() const { return last_choice_; }     // 1 relay, 2 pipelined loop, 4 short batches, tri_slab << 3, 256: the work model is still exploring this configuration
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     size_t lastApronBytes() const { return last_apron_bytes_; }
+    // device memory this handle holds right now: the volume as loaded; the optional speed copies (12-bit packed copy, apron
+    // copies); everything else (targets, tables, skip grid, staging)
+    void residentBytes(uint64_t &volume, uint64_t &copies, uint64_t &other) const;
+    // upper bound on the optional copies' total bytes (vr_set_copy_budget).  kCopyBudgetAuto: allowed while the device keeps
+    // kCopyReserveBytes (and a tenth of its memory) free after the allocation.  Lowering it frees copies that no longer fit.
+    static constexpr uint64_t kCopyBudgetAuto = ~0ull, kCopyReserveBytes = 1ull << 30;
+    void setCopyBudget(uint64_t bytes);
+    uint64_t copyBudget() const { return copy_budget_; }
     bool hasDevice() const { return device_ >= 0; }
+    void warmTrilinear();                    // pre-load the staged TRILINEAR kernel's code objects (once)
 
     int filter = 0, accum = 0, skip_empty = 0;
     int layout = 1;          // VR_LAYOUT_BRICKED: the faster HBM layout is the default (vr_set_layout)
@@ -170,6 +179,9 @@ private:
     size_t apron_bytes_ = 0, last_apron_bytes_ = 0;
     bool apron_failed_ = false;
     void refreshApron(const FrameParams &P, LaunchConfig &L);
+    uint64_t copy_budget_ = kCopyBudgetAuto;
+    uint64_t copiesBytes() const;            // optional copies resident now
+    bool copyFits(uint64_t bytes) const;     // may another optional copy of `bytes` be allocated (budget / free device memory)?
     size_t skip_grid_cells_ = 0;
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
@@ -182,6 +194,7 @@ private:
     double tile_longest_ = 0.0;              // expected samples of its longest ray
     void refreshTileSchedule(const FrameParams &P, LaunchConfig &L);
     const char *last_kernel_ = "";
+    bool tslab_warm_ = false;
     // ---- measured work model (kernel variant 0): every candidate kernel of a configuration renders the same bits, so
     // the first frames of a configuration double as measurements -- each candidate is timed a few times (HIP events on
     // the launch stream, polled without blocking), the fastest is kept until the configuration changes.
@@ -198,20 +211,23 @@ private:
         int frames_settled = 0;              // launches since it settled
         bool revalidated = false;
         uint64_t last_use = 0;               // launch counter at its last use (eviction order)
+        uint64_t gen = 0;                    // generation: results of measurements launched for an earlier life of this key (evicted and re-created, or before a re-validation) are dropped
     };
     std::map<uint64_t, TuneEntry> tune_;
     static constexpr int kTuneSlots = 12;    // asynchronous measurements that may be in flight (a burst of renderAsync calls)
-    struct TuneSlot { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t key = 0; int cand = -1; };
+    struct TuneSlot { hipEvent_t ev0 = nullptr, ev1 = nullptr; uint64_t key = 0, gen = 0; int cand = -1; };   // cand: the candidate VALUE (bit set), not its index in the entry's shuffled order
     TuneSlot tune_slot_[kTuneSlots];
     int tune_head_ = 0, tune_count_ = 0;     // ring of in-flight slots: oldest at tune_head_
     bool tune_measure_ = false;              // the launch being prepared is a measurement of candidate tune_cand_ of entry tune_key_
     uint64_t tune_key_ = 0;
-    int tune_cand_ = -1;
+    int tune_cand_ = -1;                     // candidate VALUE being measured
+    uint64_t tune_gen_ = 0, tune_gen_counter_ = 0;
     uint64_t tune_clock_ = 0, tune_last_key_ = 0;   // launches seen; the previous launch's key and for how many launches in a row
     int tune_same_key_run_ = 0;
     int last_choice_ = 0;                    // candidate bits of the last launch (vr_get_launch_choice)
     void tuneChoose(const FrameParams &P, LaunchConfig &L);
-    void tuneRecord(uint64_t key, int cand, float ms);
+    void tuneRecord(uint64_t key, uint64_t gen, int cand, float ms);
+    void tuneIssued(uint64_t key, uint64_t gen, int cand);   // a measurement of `cand` was really launched (events recorded)
     void tuneCollect();
 
     hipStream_t stream() const { return user_stream_ ? user_stream_ : own_stream_; }

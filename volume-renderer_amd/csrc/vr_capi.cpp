@@ -292,6 +292,7 @@ int vr_set_filter(vr_handle h, int filter)
     return guarded(h, [&](vr::RendererCore &c) {
         if (filter != VR_FILTER_NEAREST && filter != VR_FILTER_TRILINEAR) throw std::invalid_argument("unknown filter");
         c.filter = filter;
+        if (filter == VR_FILTER_TRILINEAR) c.warmTrilinear();       // code objects of the staged kernel: loaded here, not by a frame
     });
 }
 
@@ -350,6 +351,30 @@ int vr_get_trilinear_copy_bytes(vr_handle h, size_t *bytes)
     return guarded(h, [&](vr::RendererCore &c) {
         if (!bytes) throw std::invalid_argument("vr_get_trilinear_copy_bytes: null result");
         *bytes = c.lastApronBytes();
+    });
+}
+
+int vr_get_resident_bytes(vr_handle h, uint64_t *volume, uint64_t *copies, uint64_t *other)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        uint64_t v = 0, k = 0, o = 0;
+        c.residentBytes(v, k, o);
+        if (volume) *volume = v;
+        if (copies) *copies = k;
+        if (other) *other = o;
+    });
+}
+
+int vr_set_copy_budget(vr_handle h, uint64_t bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) { c.setCopyBudget(bytes); });
+}
+
+int vr_get_copy_budget(vr_handle h, uint64_t *bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        if (!bytes) throw std::invalid_argument("vr_get_copy_budget: null result");
+        *bytes = c.copyBudget();
     });
 }
 

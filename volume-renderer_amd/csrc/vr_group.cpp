@@ -17,12 +17,13 @@
 // (validation on a one-GPU box) or RCCL is unavailable, the shards move with hipMemcpyPeerAsync
 // behind per-member events -- same buffers, same assembly.
 //
-// Pipeline (round 3): TWO frame slots.  vr_group_render_async() enqueues frame i -- shard kernels
-// on the members' render streams into slot i & 1, the gather and the assembly on separate
-// transfer streams -- and returns; vr_group_wait() blocks until the oldest frame in flight is
-// assembled.  With one frame always in flight the gather + assembly of frame i overlap the shard
-// kernels of frame i + 1 (what bench.py's torch.distributed path does with its two slots).
-// vr_group_render() = render_async + wait: blocking, like the reference's render().
+// Pipeline: THREE frame slots, at most two frames in flight.  vr_group_render_async() enqueues frame i -- shard kernels
+// on the members' render streams into slot i % 3, the gather and the assembly on separate transfer streams -- and
+// returns; vr_group_wait() blocks until the oldest frame in flight is assembled.  With one frame always in flight the
+// gather + assembly of frame i overlap the shard kernels of frame i + 1 (what bench.py's torch.distributed path does with
+// its two slots); the third slot keeps the last COMPLETED frame (the one vr_group_framebuffer_device hands out) from
+// being the target of the frame issued next.  vr_group_render() = render_async + wait: blocking, like the reference's
+// render().  A frame whose issue fails anywhere is drained (every stream it touched) and counts as never issued.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
@@ -309,22 +310,40 @@ int vr_group_setup(vr_group_handle g, int win_w, int win_h, int fb_w, int fb_h, 
     return rc;
 }
 
-// a frame that failed half-way through its issue (some members launched, others did not): nothing of it may still be running
-// when the caller issues the next one into the same slot (round-3 advisor); the frame counts as never issued
-static void drain_members(vr_group_handle g)
+// A frame that failed half-way through its issue (some members launched, others not; a transfer or the assembly refused):
+// nothing of it may still be running when the caller issues the next one into the same slot, and the frame counts as never
+// issued.  ONE cleanup for every failure exit of the issue (round-3 / round-4 advisor): the members' render streams, their
+// transfer streams and the root's gather stream are all drained.
+static void drain_group(vr_group_handle g)
 {
     for (size_t r = 0; r < g->members.size(); r++) {
         (void)hipSetDevice(g->devices[r]);
         vr::RendererCore &c = g->members[r]->core;
         if (c.hasDevice()) (void)hipStreamSynchronize(c.streamHandle());
+        if (r < g->xfer.size() && g->xfer[r]) (void)hipStreamSynchronize(g->xfer[r]);
     }
     if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+    if (g->gather_stream) (void)hipStreamSynchronize(g->gather_stream);
     (void)hipGetLastError();
 }
+
+static int group_issue_frame(vr_group_handle g, bool &touched);
 
 int vr_group_render_async(vr_group_handle g)
 {
     if (!g) return VR_E_INVALID;
+    bool touched = false;                                              // false while only arguments / state were checked
+    const int rc = group_issue_frame(g, touched);
+    if (rc != VR_OK && touched) {
+        const std::string why = g->last_error;
+        drain_group(g);
+        g->last_error = why;
+    }
+    return rc;
+}
+
+static int group_issue_frame(vr_group_handle g, bool &touched)
+{
     const int n = (int)g->members.size();
     if (!g->frame[0]) return gfail(g, VR_E_INVALID, "vr_group_render: call vr_group_setup first");
     if (g->issued - g->completed >= kInFlight) return gfail(g, VR_E_INVALID, "vr_group_render_async: two frames in flight already (call vr_group_wait)");
@@ -337,6 +356,7 @@ int vr_group_render_async(vr_group_handle g)
     const size_t shard_floats = (size_t)g->local_rows * (size_t)g->fb_w * (size_t)channels;
     const size_t shard_bytes = shard_floats * sizeof(float);
     const bool rccl = !g->comms.empty();
+    touched = true;
     try {
         for (int r = 0; r < n; r++) {
             vr::RendererCore &c = g->members[(size_t)r]->core;
@@ -355,13 +375,10 @@ int vr_group_render_async(vr_group_handle g)
             VRG_HIP(hipEventRecord(g->rendered[s][(size_t)r], c.streamHandle()));
         }
     } catch (const vr::NoDeviceError &e) {
-        drain_members(g);
         return gfail(g, VR_E_NO_DEVICE, e.what());
     } catch (const vr::HipError &e) {
-        drain_members(g);
         return gfail(g, VR_E_HIP, e.what());
     } catch (const std::exception &e) {
-        drain_members(g);
         return gfail(g, VR_E_INVALID, e.what());
     }
     hipStream_t gs = g->gather_stream;

@@ -52,6 +52,7 @@ hipError_t launch_to_rgba8(const void *fb_rgba32f, void *out_rgba8, uint64_t pix
 
 // one empty launch per translation unit: loads every code object of the library (vr_load_shader)
 hipError_t launch_warm_modules(hipStream_t st);
+hipError_t launch_warm_tslab(hipStream_t st);     // the seven units of the LDS-staged TRILINEAR kernel (vr_tslab.hip)
 
 // TRILINEAR's apron copy: 5x4x4-stored 4x4x4 bricks (vr_device.h); `out` holds apron_voxels(nx, ny, nz) voxels.
 // order 0: x fastest (5 wide: the apron), y, z slowest; 1: x (apron), z, y slowest; 2: y (apron), z, x slowest -- the

@@ -5,17 +5,19 @@
 // gfx950 has no texture units (tex3D is compile-time unavailable), so the volume is
 // sampled in software from plain HBM allocations.
 //
-// Arithmetic contract (tests/test_parity_gpu.py): every fp32 operation is one
-// correctly rounded IEEE-754 operation in the shader's order; this file is compiled
-// with -ffp-contract=off and hipcc's default correctly rounded fp32 divide/sqrt.
-// The only fused operations are the explicit fmaf() of div_cert(), which is used
-// only for divisors that certify_div_kernel() has proven (exhaustively over all
-// 2^23 significands) to give the correctly rounded quotient.
+// Arithmetic contract (tests/test_ref_gl_goldens.py, tests/test_parity_gpu.py): the arithmetic of the reference shader AS
+// EXECUTED by a GL (Mesa 23.2.1 llvmpipe; measured per operation by oracle/ref_gl/probe_arith.py, frames pinned by
+// tests/golden/ref_gl/): every fp32 operator is one correctly rounded IEEE-754 operation in the shader's order, nothing
+// is contracted, normalize(v) = v * (1 / sqrt(dot)) with the dot summed from the last component to the first, and the
+// top view's 1 - (1 - z) is z.  Compiled with -ffp-contract=off and hipcc's default correctly rounded fp32 divide/sqrt.
+// The only fused operations are the explicit fmaf() of div_cert(), which is used only for divisors that
+// certify_div_kernel() has proven (exhaustively over all 2^23 significands) to give the correctly rounded quotient.
 //
-// Thread mapping: one pixel per lane, an 8x8 pixel tile per 64-wide wavefront
-// (8 rows x 8 columns: neighbouring rays touch neighbouring voxels), 4 wavefronts
-// (16x16 pixels) per workgroup.  Workgroups are issued in an XCD-aware order (see
-// tile_of_block) so that each XCD's private L2 serves horizontally adjacent tiles.
+// Thread mapping: one pixel per lane, an 8x8 pixel tile per 64-wide wavefront (8 rows x 8 columns: neighbouring rays
+// touch neighbouring voxels).  Fast kernel: 8 wavefronts = 32x16 pixels per 512-thread workgroup, marching in lockstep;
+// relay kernel: 4 wavefronts per 8x8 tile, two tiles per workgroup; generic kernel: 4 wavefronts = 16x16 pixels.
+// Workgroups take their tile from a host-built longest-first table dealt round-robin to the 8 XCDs (tile_schedule.cpp);
+// without a table, tile_of_block() gives every XCD whole tile rows.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -1107,4 +1107,40 @@ hipError_t launch_tslab_u16_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_
 hipError_t launch_tslab_u8_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 53, false>(P, L, vol, tf, fb, spp, st); }
 #endif
 
+// one empty kernel per translation unit (like vr_kernels.hip's warm_kernel_*): launching it makes the runtime inflate and
+// load that unit's code object.  launch_warm_tslab() touches all seven when TRILINEAR is selected (vr_set_filter /
+// vr_load_shader), so neither the first TRILINEAR frame nor the first frame of a shape the measured choice tries pays it.
+#if VR_TSLAB_TU >= 0
+#define VR_TSLAB_CAT2(a, b) a##b
+#define VR_TSLAB_CAT(a, b) VR_TSLAB_CAT2(a, b)
+__global__ void VR_TSLAB_CAT(warm_kernel_tslab, VR_TSLAB_TU)() {}
+hipError_t VR_TSLAB_CAT(launch_warm_tslab_tu, VR_TSLAB_TU)(hipStream_t st)
+{
+    hipLaunchKernelGGL(VR_TSLAB_CAT(warm_kernel_tslab, VR_TSLAB_TU), dim3(1), dim3(64), 0, st);
+    return hipGetLastError();
+}
+#endif
+#if VR_TSLAB_TU == 0
+hipError_t launch_warm_tslab_tu1(hipStream_t st);
+hipError_t launch_warm_tslab_tu2(hipStream_t st);
+hipError_t launch_warm_tslab_tu3(hipStream_t st);
+hipError_t launch_warm_tslab_tu4(hipStream_t st);
+hipError_t launch_warm_tslab_tu5(hipStream_t st);
+hipError_t launch_warm_tslab_tu6(hipStream_t st);
+hipError_t launch_warm_tslab(hipStream_t st)
+{
+    hipError_t e = launch_warm_tslab_tu0(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu1(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu2(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu3(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu4(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu5(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu6(st);
+    return e;
+}
+#elif VR_TSLAB_TU == -1
+hipError_t launch_warm_tslab(hipStream_t) { return hipSuccess; }      // single-unit build: nothing to pre-load separately
+#endif
+
 }  // namespace vr
+

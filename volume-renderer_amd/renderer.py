@@ -119,6 +119,9 @@ def load_library() -> C.CDLL:
         "vr_set_kernel_variant": (i32, [h, i32]),
         "vr_set_autotune": (i32, [h, i32]),
         "vr_get_launch_choice": (i32, [h]),
+        "vr_get_resident_bytes": (i32, [h, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "vr_set_copy_budget": (i32, [h, C.c_uint64]),
+        "vr_get_copy_budget": (i32, [h, C.POINTER(C.c_uint64)]),
         "vr_set_pack12": (i32, [h, i32]),
         "vr_get_pack12_bytes": (i32, [h, C.POINTER(C.c_size_t)]),
         "vr_set_trilinear_copy": (i32, [h, i32]),
@@ -493,7 +496,8 @@ class RendererCore:
 
     @property
     def last_launch_choice(self):
-        """candidate bits of the last launch: 1 relay, 2 pipelined loop, 4 short batches, staged-trilinear shape << 3"""
+        """candidate bits of the last launch: 1 relay, 2 pipelined loop, 4 short batches, staged-trilinear shape << 3,
+        256 = a trial frame (the measured choice is still exploring this configuration)"""
         return int(self._lib.vr_get_launch_choice(self._h))
 
     def setKernelVariant(self, variant):
@@ -511,6 +515,22 @@ class RendererCore:
         n = C.c_size_t()
         self._check(self._lib.vr_get_pack12_bytes(self._h, C.byref(n)))
         return int(n.value)
+
+    COPY_BUDGET_AUTO = 2 ** 64 - 1
+
+    def residentBytes(self):
+        """(volume, optional copies, everything else) bytes of device memory this handle holds"""
+        v, k, o = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.vr_get_resident_bytes(self._h, C.byref(v), C.byref(k), C.byref(o)))
+        return v.value, k.value, o.value
+
+    def setCopyBudget(self, nbytes):
+        self._check(self._lib.vr_set_copy_budget(self._h, C.c_uint64(int(nbytes))))
+
+    def copyBudget(self) -> int:
+        b = C.c_uint64()
+        self._check(self._lib.vr_get_copy_budget(self._h, C.byref(b)))
+        return b.value
 
     def setTrilinearCopy(self, on):
         self._check(self._lib.vr_set_trilinear_copy(self._h, int(bool(on))))
