@@ -697,6 +697,54 @@ def test_packed12_copy_takes_any_offset_when_the_range_fits_12_bits(vra, oracle)
     assert_same(got, want, what="u16 volume spanning 4097 values")
 
 
+def test_grey_transfer_function_runs_on_the_grey_ramp_kernels(vra, oracle):
+    """Round 5: a transfer function with r == g == b in every entry (the reference's own black -> white ramp; its colour
+    widget is commented out, include/UI/TransferFunction.h:4,22) is folded into the (c, a) table of the grey-ramp
+    instances: composite frames through the fast and the relay kernel, all three views, with empty-space skipping, on
+    u8 / u16 (packed copy included), equal the oracle and the generic kernel bit for bit; r == g == b in every pixel."""
+    rng = np.random.default_rng(77)
+    R = vra.renderer
+    iso = [0, 141, 149, 255]
+    grey = [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]]
+    for dtype, dims, win in ((np.uint8, (64, 48, 40), (8, 255)), (np.uint16, (48, 64, 56), (300, 3900)), (np.uint16, (64, 64, 64), (0, 4095))):
+        vol = rand_volume(rng, dims, dtype, smooth=True)
+        for view in ("default", "top", "bottom"):
+            for variant, skip in ((0, False), (0, True), (3, False), (2, False)):
+                with make_renderer(vra, (120, 96)) as r:
+                    r.setQuirks(0); r.setKernelVariant(variant); r.setSkipEmpty(skip)
+                    r.setVolume(vol); r.setWindow(*win); r.setAlpha(0.3)
+                    r.setInitialCameraRotation(view == "top", view == "bottom")
+                    r.setTransferFunction(iso, grey)
+                    lut = r.getTransferLut()
+                    assert np.array_equal(lut[:, 0], lut[:, 1]) and np.array_equal(lut[:, 0], lut[:, 2])
+                    r.cameraOrient(0.0, 0.35, -0.8)
+                    block = r.getCameraBlock()
+                    r.render()
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    assert r.last_kernel_name in FAST_KERNELS
+                    r.setKernelVariant(1); r.render()
+                    gen = r.readPixels()
+                p = oracle.OracleParams(120, 96, cam=block, alpha_scale=0.3, min_val=win[0], max_val=win[1], tf_rgba=lut,
+                                        view_top=int(view == "top"), view_bottom=int(view == "bottom"))
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                what = f"grey TF {np.dtype(dtype).name} {view} variant {variant} skip {skip}"
+                assert_same(got, want, spp, want_spp, what=what)
+                assert np.array_equal(got.view(np.uint32), gen.view(np.uint32)), what
+                assert np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+    # a coloured transfer function keeps the RGBA table path (and a grey one under MIP too): covered by
+    # test_transfer_function / test_mip_and_view_swizzles; here only that a window wider than the (c, a) table still renders
+    vol = rand_volume(rng, (40, 40, 40), np.uint16)
+    vol[3, 4, 5] = 30000
+    with make_renderer(vra, (64, 64)) as r:
+        r.setQuirks(0); r.setVolume(vol); r.setWindow(0, 20000); r.setAlpha(0.2); r.setTransferFunction(iso, grey)
+        lut = r.getTransferLut()
+        r.render()
+        got = r.readPixels()
+    want, _ = oracle.render(vol, oracle.OracleParams(64, 64, alpha_scale=0.2, min_val=0, max_val=20000, tf_rgba=lut))
+    assert_same(got, want, what="grey TF, window wider than the (c, a) table")
+
+
 def test_long_axis_volume_without_address_tables(vra, oracle):
     """nx + ny + nz > 3072: the LDS address tables (and with them the packed copy and the batched trilinear
     kernel) do not apply; the specialised kernels compute brick addresses arithmetically"""

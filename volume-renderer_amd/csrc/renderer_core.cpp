@@ -503,6 +503,9 @@ void RendererCore::setTransferFunction(const int32_t *iso, const float *rgba4, i
     if (!iso || !rgba4 || !buildSplineLUT(iso, rgba4, n, lut))
         throw std::invalid_argument("setTransferFunction: need >= 2 knots with ascending iso values");
     tf_lut_.swap(lut);
+    tf_grey_ = true;                         // r == g == b bit for bit in every entry (the reference's black -> white ramp always is)
+    for (size_t e = 0; e < tf_lut_.size() / 4 && tf_grey_; e++)
+        tf_grey_ = std::memcmp(&tf_lut_[4 * e], &tf_lut_[4 * e + 1], sizeof(float)) == 0 && std::memcmp(&tf_lut_[4 * e], &tf_lut_[4 * e + 2], sizeof(float)) == 0;
     if (device_ >= 0) {
         requireDevice("setTransferFunction");
         if (!d_tf_) check(hipMalloc(reinterpret_cast<void **>(&d_tf_), 256 * sizeof(float4)), "hipMalloc(tf)");
@@ -651,6 +654,9 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         // window value behind the 256-entry RGBA table (vr_kernels.hip: FAST_TF_WINDOW_MAX)
         L.use_lut = (width >= 2 && width <= (tf_lut_.empty() ? 4096 : FAST_TF_WINDOW_MAX) && (tf_lut_.empty() || tf_lut_.size() / 4 <= 256)) ? 1 : 0;
         L.lut_noclamp = (exact_min_ >= u_.min_val && exact_max_ <= u_.max_val) ? 1 : 0;
+        // a grey transfer function under NEAREST composite whose window fits the grey-ramp kernels' (c, a) table is folded
+        // into that table: the launch runs on the MODE 0 instances (vr_kernels.hip: raymarch_fast_kernel, LUT build)
+        P.tf_grey = (!tf_lut_.empty() && tf_grey_ && u_.is_MIP != 1 && L.use_lut != 0 && width <= 4096) ? 1 : 0;
         auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
         L.pow2_dims = (is_pow2(nx) && is_pow2(ny) && is_pow2(nz)) ? 1 : 0;
     }

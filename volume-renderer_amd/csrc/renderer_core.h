@@ -150,6 +150,7 @@ private:
     size_t spp_capacity_ = 0;
     unsigned *d_scratch_ = nullptr;          // 4 + 256 words (+ slack)
     std::vector<float> tf_lut_;              // 256 x RGBA, empty = grey ramp
+    bool tf_grey_ = false;                   // every entry of tf_lut_ has r == g == b bit for bit
     int exact_min_ = 0, exact_max_ = 65535;   // exact voxel range of the resident volume
     int row_begin_ = 0, row_end_ = -1;
     int stripe_rows_ = 0, stripe_index_ = 0, stripe_count_ = 1;

@@ -55,6 +55,7 @@ struct FrameParams {
     int32_t max_steps;             // 10000
     int32_t accum;                 // VR_ACCUM_*
     int32_t tf_len;                // 0 = grey ramp
+    int32_t tf_grey;               // 1: the transfer function is grey (r == g == b in every entry) and this launch folds it into the grey-ramp kernels' (c, a) table (NEAREST composite, window <= the table)
     int32_t skip_empty;            // exact empty-space skipping on the dilated cell-max grid
     int32_t skip_thresh;           // a cell is empty when its (dilated) max voxel <= skip_thresh
     int32_t cnx, cny, cnz;         // cells (8x8x8 voxels) per axis

@@ -318,6 +318,17 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
                     int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
                     idx = clampi(idx, 0, P.tf_len - 1);
                     reinterpret_cast<uint8_t *>(lut)[FAST_TF_ENTRIES * 16 + e] = (uint8_t)idx;
+                } else if (MODE == 0 && P.tf_grey != 0) {
+                    // a GREY transfer function (r == g == b in every entry: the reference's own colour ramp, whose colour
+                    // widget is commented out) composited: the table's (c, a) pair is the whole classification, so the
+                    // grey-ramp instance runs it -- one LDS read per sample and 3 workgroups per CU instead of MODE 2's two
+                    // reads and 2 workgroups (cfg4: 3.26 -> ms of the grey mode).  Entries with MODE 2's own operations;
+                    // r == g == b of the frame holds bit for bit because the three channels see identical operands.
+                    int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
+                    idx = clampi(idx, 0, P.tf_len - 1);
+                    const float4 t = tf[idx];
+                    const float a = t.w * P.alpha_scale;
+                    lut[2 * e + 0] = t.x * a; lut[2 * e + 1] = a;
                 } else {
                     const float a = v * P.alpha_scale;
                     lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
@@ -1042,6 +1053,12 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
                 int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
                 idx = clampi(idx, 0, P.tf_len - 1);
                 reinterpret_cast<uint8_t *>(lut)[FAST_TF_ENTRIES * 16 + e] = (uint8_t)idx;
+            } else if (MODE == 0 && P.tf_grey != 0) {            // grey transfer function on the grey-ramp instance (see the fast kernel)
+                int idx = floor_to_int_sat(v * (float)(P.tf_len - 1) + 0.5f);
+                idx = clampi(idx, 0, P.tf_len - 1);
+                const float4 t = tf[idx];
+                const float a = t.w * P.alpha_scale;
+                lut[2 * e + 0] = t.x * a; lut[2 * e + 1] = a;
             } else {
                 const float a = v * P.alpha_scale;
                 lut[2 * e + 0] = v * a; lut[2 * e + 1] = a;
@@ -1574,7 +1591,7 @@ static hipError_t launch_fast(const FrameParams &P, const LaunchConfig &L, const
 static bool relay_selected(const FrameParams &P, const LaunchConfig &L)
 {
     if (!(L.sparse_shard && L.tile_table && !L.big_offsets && !(P.skip_empty != 0 && L.skip_grid != nullptr))) return false;
-    const bool headline = !L.mip && P.tf_len <= 1 && P.view_top != 1 && P.view_bottom != 1;
+    const bool headline = !L.mip && (P.tf_len <= 1 || P.tf_grey != 0) && P.view_top != 1 && P.view_bottom != 1;
     return headline || (L.use_lut != 0 && P.nx + P.ny + P.nz <= FAST_AXIS_TAB_MAX);
 }
 
@@ -1679,7 +1696,8 @@ static hipError_t dispatch_fast2(const FrameParams &P, const LaunchConfig &L, co
 {
     if (L.mip && P.tf_len > 1) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 3>(P, L, vol, tf, fb, spp, rows, st);
     if (L.mip) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 1>(P, L, vol, tf, fb, spp, rows, st);
-    if (P.tf_len > 1) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 2>(P, L, vol, tf, fb, spp, rows, st);
+    // (a grey transfer function whose window fits the (c, a) table runs on the grey-ramp instances: FrameParams::tf_grey)
+    if (P.tf_len > 1 && P.tf_grey == 0) return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 2>(P, L, vol, tf, fb, spp, rows, st);
     return dispatch_fast3<VoxelT, LAYOUT, VIEW, BIG, 0>(P, L, vol, tf, fb, spp, rows, st);
 }
 
