@@ -663,9 +663,18 @@ def valu_roofline(key, kernel, kernel_ms):
             fam = "raymarch_tslab_kernel_half"
         cpi = cpi_all["families"][fam]["cpi"]
         issue_cycles = v["valu_wave_insts"] * cpi / 1024.0
-        return {"bound": "valu", "wave_insts": v["valu_wave_insts"], "cycles_per_inst": cpi, "issue_cycles_per_simd": round(issue_cycles, 1),
-                "shader_cycles": v["shader_cycles"], "frac": round(issue_cycles / v["shader_cycles"], 4), "kernel": kernel,
-                "unit": "VALU issue cycles / shader cycles (PMC pass: profiles/valu.json; costs: profiles/valu_cpi.json)"}
+        res = {"bound": "valu", "wave_insts": v["valu_wave_insts"], "cycles_per_inst": cpi, "issue_cycles_per_simd": round(issue_cycles, 1),
+               "shader_cycles": v["shader_cycles"], "frac": round(issue_cycles / v["shader_cycles"], 4), "kernel": kernel,
+               "unit": "VALU issue cycles / shader cycles (PMC pass: profiles/valu.json; costs: profiles/valu_cpi.json)"}
+        c = v.get("counters") or {}
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
+            # counters only, no cost model (round-4 verdict item 7): VALU-active time of the chip's 1024 SIMDs if the counter's
+            # documented unit (quad-cycles) holds, and the share of the waves' lifetime spent waiting on any instruction
+            res["measured"] = {"valu_active_frac_if_quad_cycles": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * v["shader_cycles"]), 4),
+                               "wait_inst_any_over_wave_cycles": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                               "mean_waves_per_simd_if_quad_cycles": round(c["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * v["shader_cycles"]), 2),
+                               "counters": c}
+        return res
     except Exception:
         return None
 

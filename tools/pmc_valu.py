@@ -32,6 +32,19 @@ def main():
         family = fam
         picked = name if picked is None else picked
         vals[counter] = (sum(v) / len(v), len(v))
+    # counter-only figures (no cost model), when the pass that holds them exists (tools/profile.sh collects them for the
+    # headline): SQ_ACTIVE_INST_VALU -- "cycles each wave spends executing VALU instructions", quad-cycle units per the
+    # rocprofv3 counter list --, SQ_WAIT_INST_ANY and SQ_WAVE_CYCLES (same units)
+    extra = {}
+    for counter in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        try:
+            acc = per_kernel(out, counter)
+            if picked in acc and acc[picked]:
+                extra[counter] = round(sum(acc[picked]) / len(acc[picked]), 1)
+        except SystemExit:
+            pass
+        except Exception:
+            pass
     root = Path(__file__).resolve().parent.parent
     dst = root / "profiles" / "valu.json"
     d = json.loads(dst.read_text()) if dst.exists() else {}
@@ -40,6 +53,8 @@ def main():
 
     d[key] = {"kernel": family, "instance": picked, "launches": vals["SQ_INSTS_VALU"][1], "valu_wave_insts": round(vals["SQ_INSTS_VALU"][0], 1),
               "shader_cycles": round(vals["GRBM_GUI_ACTIVE"][0] / 8.0, 1), "kernel_source_hash": kernel_source_hash()}
+    if extra:
+        d[key]["counters"] = extra
     dst.write_text(json.dumps(d, indent=1) + "\n")
     print(key, family, d[key])
 
