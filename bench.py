@@ -477,8 +477,16 @@ def main():
             # the bound that binds: VALU issue next to HBM (a committed PMC pass of this command x the hot loops' measured
             # cost per instruction); `roofline` above stays the metric's own HBM figure
             result["roofline_valu"] = valu_roofline(headline_key(args), r.last_kernel_name, kernel_ms)
-            fv = (result["roofline_valu"] or {}).get("frac")
-            result["binding_bound"] = "valu" if fv is not None and fv > result["roofline"]["frac"] else "hbm"
+            rv = result["roofline_valu"] or {}
+            # what binds, from counters where there are some: the vector L1's look-up rate when its PMC figure is there and
+            # highest (round 5: removing 7 % of the loop's VALU issue cycles moved nothing, so "valu" -- a cost MODEL -- is only
+            # named when no L1 figure contradicts it)
+            cands = {"hbm": result["roofline"]["frac"]}
+            if rv.get("frac") is not None:
+                cands["valu (modelled)"] = rv["frac"]
+            if (rv.get("l1_rate") or {}).get("frac") is not None:
+                cands["vector L1 look-up rate (measured)"] = rv["l1_rate"]["frac"]
+            result["binding_bound"] = max(cands, key=cands.get)
         if world == 1:
             # the box's own achievable HBM read rate (streaming read of the resident volume),
             # measured after the timed region ("confirm the peak on the box")
@@ -667,6 +675,12 @@ def valu_roofline(key, kernel, kernel_ms):
                "shader_cycles": v["shader_cycles"], "frac": round(issue_cycles / v["shader_cycles"], 4), "kernel": kernel,
                "unit": "VALU issue cycles / shader cycles (PMC pass: profiles/valu.json; costs: profiles/valu_cpi.json)"}
         c = v.get("counters") or {}
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            # the vector L1's address-processing rate (docs/lab-notebook.md "The second limit"; profiles/r05_q4_addressing_experiment.txt):
+            # one access per cycle per CU, so accesses / (256 CUs x shader cycles) is the share of the launch the L1s were busy
+            res["l1_rate"] = {"tcp_accesses": c["TCP_TOTAL_CACHE_ACCESSES_sum"], "frac": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * v["shader_cycles"]), 4),
+                              "accesses_per_gather": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"], 1) if c.get("SQ_INSTS_VMEM_RD") else None,
+                              "unit": "TCP_TOTAL_CACHE_ACCESSES / (256 CUs x shader cycles): one tag look-up per cycle per CU"}
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
             # counters only, no cost model (round-4 verdict item 7): VALU-active time of the chip's 1024 SIMDs if the counter's
             # documented unit (quad-cycles) holds, and the share of the waves' lifetime spent waiting on any instruction

@@ -36,7 +36,8 @@ def main():
     # headline): SQ_ACTIVE_INST_VALU -- "cycles each wave spends executing VALU instructions", quad-cycle units per the
     # rocprofv3 counter list --, SQ_WAIT_INST_ANY and SQ_WAVE_CYCLES (same units)
     extra = {}
-    for counter in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+    for counter in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum",
+                    "SQ_INSTS_VMEM_RD"):
         try:
             acc = per_kernel(out, counter)
             if picked in acc and acc[picked]:
