@@ -98,6 +98,30 @@ CASES = {
 }
 
 
+def _random_cases(n=16, seed=20260929):
+    """small whole frames over random dims / voxel types / spacings / orbit cameras / windows / opacities / modes / views:
+    the combinations nobody thought of.  Deterministic (fixed seed), so re-minting reproduces the manifest."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for k in range(n):
+        b = 1 if k % 2 == 0 else 2
+        dims = tuple(int(v) for v in rng.integers(5, 72, size=3))
+        vmax = 255 if b == 1 else 4095
+        lo = int(rng.integers(-50 if b == 2 else 0, vmax // 3))
+        hi = int(rng.integers(vmax // 2, vmax + (400 if b == 2 else 1)))
+        mode = int(rng.integers(0, 6))
+        c = dict(vol=("noise", dims, b, int(rng.integers(1, 1 << 30))), img=(16 * int(rng.integers(6, 13)), 16 * int(rng.integers(5, 10))),
+                 alpha=float(np.float32(rng.choice([1.0, 0.5, 0.11, 0.02]))), window=(lo, hi), rows=1,
+                 spacing=tuple(float(np.float32(v)) for v in np.round(rng.uniform(0.4, 2.2, size=3), 2)),
+                 cam=[(float(rng.choice([-1.0, 0.0, 0.0, 1.0])), float(np.float32(rng.uniform(-1.4, 1.4))), float(np.float32(rng.uniform(-3.1, 3.1))))],
+                 mip=int(mode == 1 or mode == 4), top=int(mode == 2 or mode == 4), bottom=int(mode == 3))
+        out[f"rnd_{k:02d}"] = c
+    return out
+
+
+CASES.update(_random_cases())
+
+
 def make_volume(spec):
     if spec[0] == "sphere":
         return oracle.gen_sphere_u8(spec[1], spec[2])
