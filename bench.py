@@ -220,12 +220,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    init_fallback = None
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
-    if os.environ.get("VR_BENCH_BACKEND", "nccl") != "nccl":
+    if os.environ.get("VR_BENCH_BACKEND", "nccl") != "nccl" or os.environ.get("VR_BENCH_FAIL_NCCL_INIT"):
         local_rank = local_rank % torch.cuda.device_count()      # validation: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -239,7 +240,16 @@ def main():
 
         backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
+            try:
+                if os.environ.get("VR_BENCH_FAIL_NCCL_INIT"):
+                    raise RuntimeError("VR_BENCH_FAIL_NCCL_INIT (test hook)")
+                dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
+            except Exception as exc:      # RCCL unusable on this node: the shards travel over gloo, and the line says so
+                init_fallback = repr(exc)[:200]
+                print(f"[bench] rank {rank}: nccl backend failed to initialise ({init_fallback}); continuing on gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", timeout=timedelta(seconds=180))
         else:
             dist.init_process_group(backend)
         # a host-side group next to RCCL: bookkeeping reductions (sample totals, timings, flags) and -- if the RCCL
@@ -340,7 +350,9 @@ def main():
     # the line says so -- a measured line on a degraded transport beats no line on the node's first RCCL contact.
     transport = {"name": "RCCL (nccl backend) over xGMI" if world > 1 and dist.get_backend() == "nccl" else ("gloo (validation)" if world > 1 else None),
                  "group": None, "host_staged": None}
-    if world > 1 and dist.get_backend() == "nccl" and not os.environ.get("VR_BENCH_SKIP_PREFLIGHT"):
+    if world > 1 and init_fallback:
+        transport["name"] = f"gloo through host memory (FALLBACK: the nccl backend failed to initialise: {init_fallback})"
+    if world > 1 and (dist.get_backend() == "nccl" or os.environ.get("VR_BENCH_FAIL_PREFLIGHT")) and not os.environ.get("VR_BENCH_SKIP_PREFLIGHT"):
         ok, why = 1, ""
         try:
             if os.environ.get("VR_BENCH_FAIL_PREFLIGHT"):
