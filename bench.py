@@ -692,7 +692,9 @@ def valu_roofline(key, kernel, kernel_ms):
             # one access per cycle per CU, so accesses / (256 CUs x shader cycles) is the share of the launch the L1s were busy
             res["l1_rate"] = {"tcp_accesses": c["TCP_TOTAL_CACHE_ACCESSES_sum"], "frac": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (256.0 * v["shader_cycles"]), 4),
                               "accesses_per_gather": round(c["TCP_TOTAL_CACHE_ACCESSES_sum"] / c["SQ_INSTS_VMEM_RD"], 1) if c.get("SQ_INSTS_VMEM_RD") else None,
-                              "unit": "TCP_TOTAL_CACHE_ACCESSES / (256 CUs x shader cycles): one tag look-up per cycle per CU"}
+                              "unit": "TCP_TOTAL_CACHE_ACCESSES / (256 CUs x shader cycles) = tag look-ups per CU per shader cycle; the L1 processes about one "
+                                      "per cycle (4 per distinct 128-B line of a gather, 16 at least: tools/ubench/tcp_rate.hip), so values near or above 1 mean saturated "
+                                      "(the two counters come from separate PMC passes: a few % of slack)"}
         if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_WAVE_CYCLES"):
             # counters only, no cost model (round-4 verdict item 7): VALU-active time of the chip's 1024 SIMDs if the counter's
             # documented unit (quad-cycles) holds, and the share of the waves' lifetime spent waiting on any instruction
