@@ -61,6 +61,13 @@ int main(int argc, char **argv)
     if (vr_set_transfer_function(h, iso, rgba, 4) != VR_OK || vr_get_transfer_lut(h, lut) != VR_OK) return fail("tf", h);
     if (vr_set_transfer_function(h, NULL, NULL, 0) != VR_OK) return fail("tf reset", h);
     printf("workgroups %d %d eye %.6f %.6f %.6f lut141 %.6f\n", wx, wy, cam[16], cam[17], cam[18], lut[141 * 4 + 3]);
+    {   /* round 5: the copy budget and what is resident, from plain C */
+        uint64_t budget = 0, vol_b = 1, copies_b = 1, other_b = 1;
+        if (vr_get_copy_budget(h, &budget) != VR_OK || budget != VR_COPY_BUDGET_AUTO) return fail("copy budget default", h);
+        if (vr_set_copy_budget(h, (uint64_t)1 << 30) != VR_OK || vr_get_copy_budget(h, &budget) != VR_OK || budget != ((uint64_t)1 << 30)) return fail("copy budget", h);
+        if (vr_set_copy_budget(h, VR_COPY_BUDGET_AUTO) != VR_OK) return fail("copy budget auto", h);
+        if (vr_get_resident_bytes(h, &vol_b, &copies_b, &other_b) != VR_OK || vol_b != 0 || copies_b != 0) return fail("resident bytes before a volume", h);
+    }
     if (!gpu) {
         if (vr_render(h) != VR_E_NO_DEVICE) return fail("render must fail without a device", h);
         printf("render without device: %s\n", vr_last_error(h));
