@@ -55,8 +55,9 @@ def parse_args():
     ap.add_argument("--volume", type=int, default=1024, help="synthetic volume edge (voxels)")
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="non-cubic synthetic volume NX NY NZ (overrides --volume)")
     ap.add_argument("--bytes", type=int, default=2, choices=(1, 2))
-    ap.add_argument("--synth", choices=("noise_ball", "sphere"), default="noise_ball",
-                    help="synthetic generator: the seeded noise ball (configs 2-4), or config 0/1's integer sphere (uint8, radius 7/16 of the edge)")
+    ap.add_argument("--synth", choices=("noise_ball", "sphere", "noise_ball_ct"), default="noise_ball",
+                    help="synthetic generator: the seeded noise ball (configs 2-4), config 0/1's integer sphere (uint8, radius 7/16 of the edge), or the "
+                         "16-bit noise ball stored the way CT data is (every voxel + 1000; default window 1000 5095)")
     ap.add_argument("--skip-empty", action="store_true", help="exact empty-space skipping (config 4)")
     ap.add_argument("--window", type=int, nargs=2, default=None, help="min max (default: full range of the generator)")
     ap.add_argument("--tf", action="store_true", help="default alpha-spline transfer function (config 4)")
@@ -290,9 +291,13 @@ def main():
     else:
         if args.synth == "sphere":
             r.generateSynthetic(R.SYNTH_SPHERE_U8, dims, 1, dims[0] * 7 // 16)
+        elif args.synth == "noise_ball_ct":
+            r.generateSynthetic(R.SYNTH_NOISE_BALL_CT, dims, 2, 0x9E3779B9)
         else:
             r.generateSynthetic(R.SYNTH_NOISE_BALL, dims, b, 0x9E3779B9)
-        win = tuple(args.window) if args.window else (0, vmax)
+        win = tuple(args.window) if args.window else ((1000, 5095) if args.synth == "noise_ball_ct" else (0, vmax))
+        if args.synth == "noise_ball_ct" and not args.window:
+            args.window = list(win)            # cpu_baseline / extras read the window from args
     r.setWindow(*win)
     if args.tf:   # the widget's default alpha knots (AlphaControlSplineWidget.cpp:56-59), black->white ramp
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
@@ -561,7 +566,7 @@ def kernel_source_hash() -> str:
 
 def headline_key(args):
     """key of this command in profiles/traffic.json / valu.json, or None for commands that have no committed PMC pass"""
-    if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12:
+    if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12 or args.synth != "noise_ball":
         return None
     return f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
 

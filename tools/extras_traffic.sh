@@ -16,6 +16,7 @@ run() {   # key, bench args...
   python tools/pmc_traffic.py "$OUT" "$KEY"
   python tools/pmc_valu.py "$OUT" "$KEY"
 }
+if [ "${1:-all}" = "one" ]; then shift; run "$@"; exit 0; fi      # tools/extras_traffic.sh one <key> <bench args...>
 [ "${1:-all}" = "trilinear_cfgs" ] || {
 run cfg1_shape --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255
 run cfg2_shape_ert_window --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095
@@ -26,6 +27,7 @@ run offaxis_deep --pose offaxis
 run headline_without_pack12 --no-pack12
 run shallow_alpha1_ert --alpha 1.0
 run trilinear_offaxis_deep --filter trilinear --pose offaxis
+run headline_offset1000 --synth noise_ball_ct
 }
 run cfg1_shape_trilinear --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --filter trilinear
 run cfg2_shape_ert_window_trilinear --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --filter trilinear
