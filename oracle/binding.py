@@ -40,6 +40,7 @@ class _Params(C.Structure):
         ("tf_rgba", C.POINTER(C.c_float)), ("tf_len", C.c_int32),
         ("threads", C.c_int32),
         ("arith", C.c_int32),
+        ("lerp_unfused", C.c_int32),
     ]
 
 
@@ -117,6 +118,7 @@ class OracleParams:
     tf_rgba: np.ndarray | None = None
     threads: int = 1
     arith: int = 0          # 0 = MESA (the executed reference: the contract), 1 = SPEC (specification text)
+    lerp_unfused: int = 0   # TRILINEAR: 1 = three roundings per lerp (rounds 1-4; measurement only), 0 = one fma (the definition)
 
 
 def render(volume: np.ndarray, p: OracleParams, want_spp: bool = False, out: np.ndarray | None = None):
@@ -149,6 +151,7 @@ def render(volume: np.ndarray, p: OracleParams, want_spp: bool = False, out: np.
         q.tf_len = tf.shape[0]
     q.threads = p.threads
     q.arith = p.arith
+    q.lerp_unfused = p.lerp_unfused
     rgba = out if out is not None else np.zeros((p.img_h, p.img_w, 4), dtype=np.float32)
     spp = np.zeros((p.img_h, p.img_w), dtype=np.uint32) if want_spp else None
     total = C.c_uint64()

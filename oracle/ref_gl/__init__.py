@@ -28,7 +28,7 @@ class _Job(C.Structure):
         ("cam", C.c_float * 21), ("alpha_scale", C.c_float), ("voxel_size", C.c_float * 3),
         ("min_val", C.c_int32), ("max_val", C.c_int32),
         ("is_mip", C.c_int32), ("view_top", C.c_int32), ("view_bottom", C.c_int32),
-        ("tex_filter", C.c_int32), ("clear_value", C.c_float),
+        ("tex_filter", C.c_int32), ("clear_value", C.c_float), ("tex_float", C.c_int32),
     ]
 
 
@@ -73,13 +73,14 @@ def render(volume: np.ndarray, img, cam, *, alpha_scale=1.0, voxel_size=(1.0, 1.
     Returns rgba[H, W, 4] float32, row 0 = bottom."""
     lib = load()
     v = np.ascontiguousarray(volume)
-    assert v.ndim == 3 and v.dtype in (np.uint8, np.uint16)
+    assert v.ndim == 3 and v.dtype in (np.uint8, np.uint16, np.float32)
     nz, ny, nx = v.shape
     W, H = img
     j = _Job()
     j.shader_path = str(shader_path).encode()
     j.volume = v.ctypes.data
     j.nx, j.ny, j.nz, j.bytes_per_voxel = nx, ny, nz, v.dtype.itemsize
+    j.tex_float = 1 if v.dtype == np.float32 else 0     # (the TRILINEAR cross-check: R32F + a `sampler3D` variant of the shader)
     j.fb_w, j.fb_h = W, H
     j.win_w, j.win_h = window_size if window_size is not None else (W, H)
     cam = np.ascontiguousarray(cam, dtype=np.float32)

@@ -121,6 +121,45 @@ def _random_cases(n=16, seed=20260929):
 
 CASES.update(_random_cases())
 
+# ---- TRILINEAR (north-star's filter; SURVEY F1/F4: the reference's integer texture cannot be filtered, so it has no TRILINEAR
+# semantics of its own).  What a real GL's linear filter computes is measured with ONE token of the shader changed at run
+# time -- `usampler3D` -> `sampler3D` -- over an R32F texture holding the same voxel values, MIN/MAG GL_LINEAR (the
+# reference's own filter state), everything else of the shader and the call sequence untouched.  The oracle's TRILINEAR
+# (GL's linear rule, each lerp one fma) and the HIP kernels reproduce these frames bit for bit.
+TRI = dict(tri=1)
+CASES.update({
+    "tri_cfg0_a0.05": dict(vol=SPH64, img=(256, 256), alpha=0.05, window=(0, 255), rows=1, **TRI),
+    "tri_cfg0_a1_orbit": dict(vol=SPH64, img=(256, 256), alpha=1.0, window=(0, 255), rows=1, cam=ORBIT_A, **TRI),
+    "tri_cfg0_mip_top": dict(vol=SPH64, img=(256, 256), alpha=0.5, window=(0, 255), rows=1, mip=1, top=1, cam=ORBIT_B, **TRI),
+    "tri_cfg0_bottom_inside": dict(vol=SPH64, img=(256, 256), alpha=0.05, window=(0, 255), rows=1, bottom=1, cam=ORBIT_A, eye=(0.11, -0.07, 0.23), **TRI),
+    "tri_u16_small_window": dict(vol=SMALL16, img=(320, 240), alpha=0.05, window=(0, 4095), spacing=(1.0, 1.0, 1.5), rows=1, cam=ORBIT_A, **TRI),
+    "tri_u16_small_mip": dict(vol=SMALL16, img=(320, 240), alpha=0.7, window=(-800, 2000), spacing=(1.0, 0.8, 1.5), rows=1, mip=1, cam=ORBIT_B, **TRI),
+    "tri_u8_odd_dims": dict(vol=ODD8, img=(304, 208), alpha=0.03, window=(0, 255), rows=1, cam=ORBIT_B, **TRI),
+    "tri_cfg1_shape_a0.02": dict(vol=SPH256, img=(1280, 720), alpha=0.02, window=(0, 255), rows=40, **TRI),
+    "tri_cfg2_shape_window": dict(vol=CFG2, img=(1920, 1080), alpha=0.05, window=(0, 4095), rows=60, **TRI),
+    "tri_cfg2_shape_offaxis": dict(vol=CFG2, img=(1920, 1080), alpha=0.01, window=(0, 4095), rows=60, cam=OFFAXIS, **TRI),
+})
+for _k, _c in _random_cases(8, seed=20260930).items():
+    CASES["tri_" + _k] = dict(_c, **TRI)
+
+_TRI_SHADER = None
+
+
+def tri_shader_path():
+    """the reference shader with its one `usampler3D` spelled `sampler3D`, in a temporary file (deleted at exit; never in the repo)"""
+    global _TRI_SHADER
+    if _TRI_SHADER is None:
+        import atexit
+        import tempfile
+        src = ref_gl.SHADER_PATH.read_text()
+        assert src.count("usampler3D") == 1
+        f = tempfile.NamedTemporaryFile("w", suffix=".cs", delete=False)
+        f.write(src.replace("usampler3D", "sampler3D"))
+        f.close()
+        atexit.register(lambda: os.path.exists(f.name) and os.unlink(f.name))
+        _TRI_SHADER = f.name
+    return _TRI_SHADER
+
 
 def make_volume(spec):
     if spec[0] == "sphere":
@@ -139,7 +178,12 @@ def run_gl(c, vol, **over):
     if "eye" in c:
         cam = cam.copy()
         cam[16:19] = np.asarray(c["eye"], dtype=np.float32)
-    frame = ref_gl.render(vol, c["img"], cam, alpha_scale=c["alpha"], voxel_size=c.get("spacing", (1.0, 1.0, 1.0)), min_val=lo, max_val=hi,
+    if c.get("tri"):      # a real GL's linear filter: sampler3D variant + R32F texture of the same values + the reference's GL_LINEAR
+        over = dict(dict(tex_filter=ref_gl.GL_LINEAR, shader_path=tri_shader_path()), **over)
+        vol_gl = vol.astype(np.float32)
+    else:
+        vol_gl = vol
+    frame = ref_gl.render(vol_gl, c["img"], cam, alpha_scale=c["alpha"], voxel_size=c.get("spacing", (1.0, 1.0, 1.0)), min_val=lo, max_val=hi,
                           is_mip=c.get("mip", 0), view_top=c.get("top", 0), view_bottom=c.get("bottom", 0), clear_value=CLEAR, **over)
     return frame, cam
 
@@ -206,6 +250,8 @@ def main():
             "img": list(c["img"]), "cam_f32_hex": [np.float32(v).tobytes().hex() for v in cam], "cam": [float(v) for v in cam],
             "alpha": c["alpha"], "spacing": list(c.get("spacing", (1.0, 1.0, 1.0))), "window": list(c["window"]), "uploaded_window": [lo, hi],
             "mip": c.get("mip", 0), "top": c.get("top", 0), "bottom": c.get("bottom", 0), "row_stride": c["rows"],
+            "filter": "trilinear" if c.get("tri") else "nearest",
+            "shader_variant": "usampler3D -> sampler3D (one token), R32F texture of the same voxel values, GL_LINEAR" if c.get("tri") else "unmodified",
             "written_extent": [wlim, hlim], "frame_sha256": hashlib.sha256(frame.tobytes()).hexdigest(),
             "pixels_with_alpha": int((frame[..., 3] > 0).sum()), "gl_seconds": round(dt, 2),
         }

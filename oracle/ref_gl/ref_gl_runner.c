@@ -158,6 +158,8 @@ typedef struct refgl_job {
     int32_t is_mip, view_top, view_bottom;   /* loc 4/5/6 */
     int32_t tex_filter;            /* GL_LINEAR = reference; GL_NEAREST = stated deviation */
     float clear_value;             /* target is pre-filled with this (to see untouched pixels) */
+    int32_t tex_float;             /* 0 = the reference's R8UI / R16UI upload; 1 = `volume` holds floats, uploaded as GL_R32F (the
+                                      TRILINEAR cross-check only: a filterable texture for a shader with `sampler3D`) */
 } refgl_job;
 
 static int slurp(const char *path, char **out)
@@ -222,8 +224,11 @@ int refgl_render(const refgl_job *j, float *out_rgba)
     glTexParameteri(GL_TEXTURE_3D, GL_TEXTURE_MAG_FILTER, j->tex_filter);
     glTexParameteri(GL_TEXTURE_3D, GL_TEXTURE_MIN_FILTER, j->tex_filter);
     if (j->nx % 4 != 0) glPixelStorei(GL_UNPACK_ALIGNMENT, 1);
-    glTexImage3D(GL_TEXTURE_3D, 0, j->bytes_per_voxel == 1 ? GL_R8UI : GL_R16UI, j->nx, j->ny, j->nz, 0,
-                 GL_RED_INTEGER, j->bytes_per_voxel == 1 ? GL_UNSIGNED_BYTE : GL_UNSIGNED_SHORT, j->volume);
+    if (j->tex_float)
+        glTexImage3D(GL_TEXTURE_3D, 0, GL_R32F, j->nx, j->ny, j->nz, 0, GL_RED, GL_FLOAT, j->volume);
+    else
+        glTexImage3D(GL_TEXTURE_3D, 0, j->bytes_per_voxel == 1 ? GL_R8UI : GL_R16UI, j->nx, j->ny, j->nz, 0,
+                     GL_RED_INTEGER, j->bytes_per_voxel == 1 ? GL_UNSIGNED_BYTE : GL_UNSIGNED_SHORT, j->volume);
     glPixelStorei(GL_UNPACK_ALIGNMENT, 4);
     if (glGetError() != GL_NO_ERROR) { fail("%s", "GL error during texture / UBO set-up"); goto out; }
 

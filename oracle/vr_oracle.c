@@ -21,7 +21,7 @@
  *   i = clamp(int(floor(u*N)), 0, N-1)          (RendererCore.cpp:408-419)
  * TRILINEAR (north-star mode, no reference semantics) is GL's linear rule:
  *   u' = u*N - 0.5, i0 = floor(u'), f = u' - i0, both taps clamped to edge,
- *   lerp(a,b,t) = a + t*(b-a), x first, then y, then z.
+ *   lerp(a,b,t) = fma(t, b-a, a) (one rounding: the executed GL's linear filter), x first, then y, then z.
  */
 #include "vr_oracle.h"
 
@@ -183,10 +183,18 @@ static inline float sample_volume(const vro_params *p, const frame_consts *fc, c
     float c010 = fetch_voxel(p, i0, j1, k0), c110 = fetch_voxel(p, i1, j1, k0);
     float c001 = fetch_voxel(p, i0, j0, k1), c101 = fetch_voxel(p, i1, j0, k1);
     float c011 = fetch_voxel(p, i0, j1, k1), c111 = fetch_voxel(p, i1, j1, k1);
-    float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-    float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-    float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-    return c0 + az * (c1 - c0);
+    if (p->lerp_unfused) {  /* rounds 1-4: three separately rounded operations per lerp (kept as a measurement) */
+        float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
+        float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
+        float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
+        return c0 + az * (c1 - c0);
+    }
+    /* lerp(a, b, t) = fma(t, b - a, a): what a real GL's linear filter computes (Mesa llvmpipe, GL_LINEAR on an R32F
+       texture through the reference shader with usampler3D -> sampler3D: bit-identical, tests/golden/ref_gl/tri_*) */
+    float c00 = fmaf(ax, c100 - c000, c000), c10 = fmaf(ax, c110 - c010, c010);
+    float c01 = fmaf(ax, c101 - c001, c001), c11 = fmaf(ax, c111 - c011, c011);
+    float c0 = fmaf(ay, c10 - c00, c00), c1 = fmaf(ay, c11 - c01, c01);
+    return fmaf(az, c1 - c0, c0);
 }
 
 /* window mapping, VolumeRenderer.cs:122-124 (Q4: max==min defined as 0) */

@@ -75,6 +75,8 @@ typedef struct vro_params {
     int32_t tf_len;
     int32_t threads;                   /* <=1: scalar single thread; >1: OpenMP rows */
     int32_t arith;                     /* VRO_ARITH_* */
+    int32_t lerp_unfused;              /* TRILINEAR: 0 = each lerp is one fma (the definition: the executed GL's linear filter);
+                                          1 = a + t * (b - a) in three roundings (rounds 1-4; measurement only) */
 } vro_params;
 
 /* Renders into rgba (img_h*img_w*4 floats, row 0 = bottom, GL convention).

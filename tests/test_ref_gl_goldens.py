@@ -61,6 +61,7 @@ def oracle_params(oracle, c, **kw):
     lo, hi = c["uploaded_window"]
     return oracle.OracleParams(W, H, cam=cam_of(c), alpha_scale=c["alpha"], voxel_size=tuple(c["spacing"]), min_val=lo, max_val=hi,
                                is_mip=c["mip"], view_top=c["top"], view_bottom=c["bottom"], trunc_grid=1,
+                               filter=1 if c.get("filter") == "trilinear" else 0,
                                threads=min(os.cpu_count() or 1, 16), **kw)
 
 
@@ -153,6 +154,23 @@ def test_goldens_reproduce_under_llvmpipe_when_the_reference_is_here(oracle):
         assert hashlib.sha256(frame.tobytes()).hexdigest() == CASES[name]["frame_sha256"], name
 
 
+def test_live_differential_oracle_vs_llvmpipe_on_random_frames():
+    """authoring container only: 250 random configurations (oracle/ref_gl/fuzz_oracle_vs_gl.py; 220 000 of them are on
+    record in profiles/r05_oracle_vs_executed_reference_fuzz.txt) rendered by the reference under llvmpipe and by the
+    oracle -- every frame bit for bit"""
+    try:
+        from oracle import ref_gl
+    except Exception as e:   # pragma: no cover
+        pytest.skip(f"ref_gl unavailable: {e}")
+    if not ref_gl.available():
+        pytest.skip("no /root/reference or no Mesa swrast driver here (GPU box)")
+    import subprocess
+    import sys
+    tool = Path(__file__).resolve().parents[1] / "oracle" / "ref_gl" / "fuzz_oracle_vs_gl.py"
+    proc = subprocess.run([sys.executable, str(tool), "250", "77"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and " 0 frames with a bit-different pixel" in proc.stdout, proc.stdout[-800:] + proc.stderr[-800:]
+
+
 # ------------------------------------------------------------------------------------------ HIP path vs reference (GPU)
 def render_hip(vra, oracle, c, variant=0):
     R = vra.renderer
@@ -171,6 +189,7 @@ def render_hip(vra, oracle, c, variant=0):
         r.setWindow(*c["window"])                                          # GUI values; the core adds the +1000
         r.setAlpha(c["alpha"])
         r.setMIP(bool(c["mip"]))
+        r.setFilter(R.FILTER_TRILINEAR if c.get("filter") == "trilinear" else R.FILTER_NEAREST)
         r.setInitialCameraRotation(bool(c["top"]), bool(c["bottom"]))      # also resets the camera (RendererCore.cpp:94)
         r.setCameraBlock(cam_of(c))
         r.render()
@@ -197,3 +216,41 @@ def test_hip_kernel_variants_reproduce_the_executed_reference(vra, oracle, name,
     c = CASES[name]
     frame, kernel = render_hip(vra, oracle, c, variant)
     assert hashlib.sha256(np.ascontiguousarray(frame).tobytes()).hexdigest() == c["frame_sha256"], f"{name} [{kernel}]"
+
+
+# ------------------------------------------------------------------------------------------ TRILINEAR: a real GL's linear filter
+TRI = sorted(n for n, c in CASES.items() if c.get("filter") == "trilinear")
+
+
+def test_trilinear_goldens_are_the_one_token_variant_and_say_so():
+    assert len(TRI) >= 15
+    for n in TRI:
+        assert "usampler3D -> sampler3D" in CASES[n]["shader_variant"] and "GL_LINEAR" in CASES[n]["shader_variant"]
+    assert all(CASES[n]["shader_variant"] == "unmodified" for n in CASES if n not in TRI)
+
+
+@pytest.mark.parametrize("name", ["tri_cfg0_a0.05", "tri_u16_small_window", "tri_cfg1_shape_a0.02"])
+def test_three_rounding_lerps_are_within_tolerance_but_not_the_gl_filter(oracle, name):
+    """rounds 1-4 defined the lerp as a + t * (b - a) in three roundings: within 1e-6 of the executed GL's filter (one fma per
+    lerp), never the same frame -- the distance on record"""
+    c = CASES[name]
+    vol = volume_of(oracle, c)
+    W, H = c["img"]
+    rows, want = golden_rows(name)
+    p = oracle_params(oracle, c, lerp_unfused=1)
+    frame = np.zeros((H, W, 4), dtype=np.float32)
+    for y in rows:
+        p.row_begin, p.row_end = int(y), int(y) + 1
+        oracle.render(vol, p, out=frame)
+    d = np.abs(frame[rows] - want)
+    assert (frame[rows].view(np.uint32) != want.view(np.uint32)).any() and d.max() < 1e-5, float(d.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2, 6, 7], ids=["generic", "batched", "staged", "unstaged"])
+@pytest.mark.parametrize("name", ["tri_cfg0_a0.05", "tri_cfg0_mip_top", "tri_cfg0_bottom_inside", "tri_u16_small_window", "tri_u8_odd_dims", "tri_rnd_02"])
+def test_hip_trilinear_kernel_families_reproduce_the_gl_linear_filter(vra, oracle, name, variant):
+    c = CASES[name]
+    frame, kernel = render_hip(vra, oracle, c, variant)
+    assert hashlib.sha256(np.ascontiguousarray(frame).tobytes()).hexdigest() == c["frame_sha256"], f"{name} [{kernel}]"
+

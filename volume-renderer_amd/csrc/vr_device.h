@@ -130,6 +130,13 @@ __device__ __forceinline__ float fetch_voxel(const FrameParams &P, const VoxelT 
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// The TRILINEAR lerp, a + t * (b - a) as ONE fused multiply-add: fma(t, b - a, a).  This is the arithmetic of a real GL's
+// linear filter -- Mesa llvmpipe's GL_LINEAR on an R32F 3-D texture (lp_build_lerp -> fmuladd), measured bit for bit through
+// the reference shader with `usampler3D` -> `sampler3D` (tests/golden/ref_gl/tri_*, oracle/ref_gl/mint_ref_gl_goldens.py) --
+// and what the oracle's TRILINEAR is defined as since round 5 (rounds 1-4: three separately rounded operations).  The
+// compositing and every NEAREST operation stay unfused: the executed reference does not contract them.
+__device__ __forceinline__ float tri_lerp(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
+
 // float -> int with the saturation the oracle's (int64) floor + clamp produces
 __device__ __forceinline__ int floor_to_int_sat(float f)
 {

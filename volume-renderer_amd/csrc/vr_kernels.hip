@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256) void raymarch_generic_kernel(const FrameParams
                         c100 = tap(x1 + y0 + z0); c110 = tap(x1 + y1 + z0); c101 = tap(x1 + y0 + z1); c111 = tap(x1 + y1 + z1);
                     }
                 }
-                const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-                const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-                const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-                s = c0 + az * (c1 - c0);
+                const float c00 = tri_lerp(c000, c100, ax), c10 = tri_lerp(c010, c110, ax);
+                const float c01 = tri_lerp(c001, c101, ax), c11 = tri_lerp(c011, c111, ax);
+                const float c0 = tri_lerp(c00, c10, ay), c1 = tri_lerp(c01, c11, ay);
+                s = tri_lerp(c0, c1, az);
             }
             fetches++;
             // window (VolumeRenderer.cs:122-124; Q4: max==min defined as 0)
@@ -820,10 +820,10 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
         const float c000 = (float)(tv[0] & M), c010 = (float)(tv[1] & M), c001 = (float)(tv[2] & M), c011 = (float)(tv[3] & M);
         const float c100 = (float)(pair ? tv[0] >> SH : tv[4]), c110 = (float)(pair ? tv[1] >> SH : tv[5]);
         const float c101 = (float)(pair ? tv[2] >> SH : tv[6]), c111 = (float)(pair ? tv[3] >> SH : tv[7]);
-        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-        float s = c0 + az * (c1 - c0);
+        const float c00 = tri_lerp(c000, c100, ax), c10 = tri_lerp(c010, c110, ax);
+        const float c01 = tri_lerp(c001, c101, ax), c11 = tri_lerp(c011, c111, ax);
+        const float c0 = tri_lerp(c00, c10, ay), c1 = tri_lerp(c01, c11, ay);
+        float s = tri_lerp(c0, c1, az);
         s = fminf(fmaxf(s, P.fmin), P.fmax);                 // never NaN here
         s = div_cert(s - P.fmin, P.fden, P.rden);
         a = s * P.alpha_scale;

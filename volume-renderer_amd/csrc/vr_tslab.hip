@@ -1,8 +1,8 @@
 // vr_tslab.hip -- TRILINEAR ray-march with the volume's bricks staged in LDS, for gfx950 (MI355X / CDNA4).
 //
 // Same arithmetic as every other trilinear path of this library (GL's linear rule on the shader's sample positions,
-// VolumeRenderer.cs:121 with the filter state of src/RendererCore.cpp:414-415; fixed lerp order x, y, z as in
-// oracle/vr_oracle.c; iterative position accumulation; checked head + safe prefix + checked tail, vr_device.h).
+// VolumeRenderer.cs:121 with the filter state of src/RendererCore.cpp:414-415; fixed lerp order x, y, z, each lerp one fma, as in
+// oracle/vr_oracle.c and as Mesa llvmpipe's GL_LINEAR computes it; iterative position accumulation; checked head + safe prefix + checked tail, vr_device.h).
 // What changes is where the prefix's eight taps per sample come from, and in which ORDER a workgroup's rays advance.
 //
 // Why: the batched trilinear kernel (vr_kernels.hip) issues 4-8 scattered global gathers per sample; on gfx950 the
@@ -267,10 +267,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     auto shade = [&](const uint32_t *tv, float ax, float ay, float az, float &c, float &cg, float &cb, float &a) {
         const float c000 = (float)tv[0], c100 = (float)tv[1], c010 = (float)tv[2], c110 = (float)tv[3];
         const float c001 = (float)tv[4], c101 = (float)tv[5], c011 = (float)tv[6], c111 = (float)tv[7];
-        const float c00 = c000 + ax * (c100 - c000), c10 = c010 + ax * (c110 - c010);
-        const float c01 = c001 + ax * (c101 - c001), c11 = c011 + ax * (c111 - c011);
-        const float c0 = c00 + ay * (c10 - c00), c1 = c01 + ay * (c11 - c01);
-        classify(c0 + az * (c1 - c0), c, cg, cb, a);
+        const float c00 = tri_lerp(c000, c100, ax), c10 = tri_lerp(c010, c110, ax);
+        const float c01 = tri_lerp(c001, c101, ax), c11 = tri_lerp(c011, c111, ax);
+        const float c0 = tri_lerp(c00, c10, ay), c1 = tri_lerp(c01, c11, ay);
+        classify(tri_lerp(c0, c1, az), c, cg, cb, a);
     };
     auto accumulate = [&](float c, float cg, float cb, float a) {
         if (MODE == 1) {
@@ -841,11 +841,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     prepare();
                     const float ax = wx, ay = wy, az = wz;
                     float c00, c10, c01, c11;
-                    // (round 5, a bounded experiment: the seven lerps as ONE fma each -- a + t * (b - a) as fma(t, b - a, a), within
-                    // north-star's 1e-4 but not the oracle's bits -- measured 1.125 -> 1.098 ms at the default pose (-2.4 %), 1.549 ->
-                    // 1.529 off-axis, 8-bit volumes 0.929 -> 0.891 / 1.177 -> 1.122, 256^3 0.239 -> 0.226: under the 6 % the
-                    // experiment was given, so the lerps stay three correctly rounded operations, the oracle's definition)
-                    auto lerp = [](float a, float b, float t) { return a + t * (b - a); };
+                    // the seven lerps are one fma each (vr_device.h: tri_lerp): the arithmetic of a real GL's linear filter, and
+                    // 2.4 % (16-bit) to 5.5 % (8-bit, small volumes) fewer issue cycles than three operations each
+                    // (profiles/r05_fma_lerp_experiment.txt)
+                    auto lerp = [](float a, float b, float t) { return tri_lerp(a, b, t); };
                     if (sizeof(VoxelT) == 1) {
                         // integer -> float without v_cvt (4.4 cycles each, eight per sample): 2^23 | v IS the float 2^23 + v for
                         // v < 2^23 (v_or_b32: 2.3 cycles); the x differences need no un-biasing -- (2^23 + a) - (2^23 + b) == a - b
@@ -855,8 +854,9 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                         const float b000 = __uint_as_float(v000 | k_magic_u), b100 = __uint_as_float(v100 | k_magic_u), b010 = __uint_as_float(v010 | k_magic_u), b110 = __uint_as_float(v110 | k_magic_u);
                         const float b001 = __uint_as_float(v001 | k_magic_u), b101 = __uint_as_float(v101 | k_magic_u), b011 = __uint_as_float(v011 | k_magic_u), b111 = __uint_as_float(v111 | k_magic_u);
                         const float c000 = b000 - k_magic_f, c010 = b010 - k_magic_f, c001 = b001 - k_magic_f, c011 = b011 - k_magic_f;
-                        c00 = c000 + ax * (b100 - b000); c10 = c010 + ax * (b110 - b010);
-                        c01 = c001 + ax * (b101 - b001); c11 = c011 + ax * (b111 - b011);
+                        // (b - a of two biased taps is the exact difference of the voxels, as before)
+                        c00 = __builtin_fmaf(ax, b100 - b000, c000); c10 = __builtin_fmaf(ax, b110 - b010, c010);
+                        c01 = __builtin_fmaf(ax, b101 - b001, c001); c11 = __builtin_fmaf(ax, b111 - b011, c011);
                     } else {
                         const float c000 = (float)v000, c100 = (float)v100, c010 = (float)v010, c110 = (float)v110;
                         const float c001 = (float)v001, c101 = (float)v101, c011 = (float)v011, c111 = (float)v111;
