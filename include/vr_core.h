@@ -36,6 +36,11 @@ enum {
     VR_E_NOMEM = 5
 };
 
+/* NEAREST: what the reference's texture() yields -- its GL_LINEAR on an integer texture is refused by a conformant GL (all-zero
+   frame) and read as NEAREST by the drivers it was written on; frames are bit-identical to the reference shader executed under
+   Mesa llvmpipe (tests/golden/ref_gl/).  TRILINEAR (north-star's filter; no reference semantics): GL's linear rule with
+   CLAMP_TO_EDGE, x then y then z, each lerp one fma -- bit-identical to llvmpipe's GL_LINEAR on an R32F texture of the same
+   voxels through the reference shader with `usampler3D` spelled `sampler3D` (tests/golden/ref_gl/tri_*). */
 enum { VR_FILTER_NEAREST = 0, VR_FILTER_TRILINEAR = 1 };
 enum { VR_ACCUM_ITERATIVE = 0, VR_ACCUM_CLOSED_FORM = 1 };
 enum { VR_LAYOUT_LINEAR = 0, VR_LAYOUT_BRICKED = 1 };
