@@ -933,7 +933,8 @@ void RendererCore::refreshPacked12(FrameParams &P, LaunchConfig &L)
     const size_t bytes = voxels / 2 * 3;
     if (bytes + 16 >= (1ull << 32)) return;
     if (!d_vol12_) {
-        if (vol12_failed_ || !copyFits(bytes + 16)) return;
+        if (vol12_failed_) return;
+        if (!copyFits(bytes + 16)) { vol12_failed_ = true; return; }      // (not asked again every frame; vr_set_copy_budget / the next volume re-arm it)
         if (hipMalloc(&d_vol12_, bytes + 16) != hipSuccess) {     // an optimisation only: render from the volume as loaded
             (void)hipGetLastError();
             d_vol12_ = nullptr;
@@ -966,7 +967,7 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     const uint64_t bytes = apron_voxels(res_dims_[0], res_dims_[1], res_dims_[2]) * (uint64_t)res_bytes_;
     if (bytes + 16 >= (1ull << 32) && !tri_slab_candidate(P, L)) return;   // the batched kernel gathers through a 32-bit buffer descriptor
     if (!d_apron_) {
-        if (!copyFits(bytes + 16)) return;                             // over the budget / too little device memory left: not an error
+        if (!copyFits(bytes + 16)) { apron_failed_ = true; return; }   // over the budget / too little device memory left: not an error, and not asked again every frame
         if (hipMalloc(&d_apron_, bytes + 16) != hipSuccess) {         // an optimisation only
             (void)hipGetLastError();
             d_apron_ = nullptr;
