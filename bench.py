@@ -333,6 +333,7 @@ def main():
     locals_ = [torch.zeros((plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)]
     gathered = [torch.empty((world * plan.local_rows, W, C4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
     frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(nslots)] if world > 1 else [None]
+    torch.cuda.synchronize(dev)        # the targets' zero fills ran on torch's default stream: done before any kernel on `stream` writes them
     ev_rendered = [torch.cuda.Event() for _ in range(nslots)]
     ev_gathered = [torch.cuda.Event() for _ in range(nslots)]
     local = locals_[0]

@@ -166,6 +166,7 @@ def test_grey_alpha_target_is_the_same_frame_in_half_the_bytes(vra, oracle):
             r.setFramebufferExternal(0); r.setFramebufferFormat(R.FB_RGBA32F)
             r.render(); want = r.readPixels().copy()
             ga = torch.full((H, W, 2), -1.0, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()          # the fill runs on torch's stream, the kernel on the renderer's own (non-blocking) one
             r.setFramebufferExternal(ga.data_ptr()); r.setFramebufferFormat(R.FB_GREYALPHA32F)
             r.render(); torch.cuda.synchronize()
             got = sharding.expand_grey_alpha(ga).cpu().numpy()
@@ -191,6 +192,7 @@ def test_external_target_stream_and_compact_shard(vra, oracle):
         stream = torch.cuda.Stream()
         r.setStream(stream.cuda_stream)
         tgt = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()              # (the zero fill is on torch's default stream: it must not land after the frame)
         r.setFramebufferExternal(tgt.data_ptr())
         assert r.framebufferDevice() == tgt.data_ptr()
         r.renderAsync()
@@ -198,6 +200,7 @@ def test_external_target_stream_and_compact_shard(vra, oracle):
         assert np.array_equal(tgt.cpu().numpy().view(np.uint32), full.view(np.uint32))
         # compact shard: rows 16..47 land at local rows 0..31 of a 32-row target
         part = torch.zeros((32, W, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         r.setFramebufferExternal(part.data_ptr())
         r.setFramebufferCompact(True)
         r.setRowRange(16, 48)
@@ -269,6 +272,7 @@ def test_assemble_shards_matches_the_index_path(vra, oracle, mode, world, channe
         r.setFramebufferCompact(True)
         plans = [sharding.plan_rows(H, world, k, mode, 16) for k in range(world)]
         gathered = torch.full((world * plans[0].local_rows, W, channels), -7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
         for k, plan in enumerate(plans):
             sharding.apply_plan(r, plan)
             shard = gathered[k * plan.local_rows:(k + 1) * plan.local_rows]
