@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """kernel ms of BASELINE config 4 (2048^3 u8 @ 3840x2160) in the grey / transfer-function modes with and without exact
-empty-space skipping, at sustained clocks:  tools/cfg4_ms.py [N=2048] [W H]"""
+empty-space skipping, at sustained clocks:  tools/cfg4_ms.py [N=2048] [W H] [trilinear [kernel variant]]"""
 import importlib, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -12,6 +12,9 @@ r = vra.RendererCore(0)
 r.setup((W, H)); r.loadShader("x"); r.setQuirks(0)
 r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), 1, 0x9E3779B9)
 r.setWindow(8, 255); r.setAlpha(0.004)
+if len(sys.argv) > 4 and sys.argv[4] == "trilinear":
+    r.setFilter(R.FILTER_TRILINEAR)
+    r.setKernelVariant(int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 
 
 def ms(n=10):

@@ -1074,15 +1074,20 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
     L.skip_grid = nullptr;
     L.skip_grid_bytes = 0;
     P.skip_empty = 0;
-    if (!skip_empty || !fast_path_eligible(P, L)) return;
+    // TRILINEAR on the LDS-staged kernel skips whole brick layers of a tile (vr_tslab.hip: SKIP): same grid, same threshold --
+    // an interpolated value never exceeds its largest tap, and the classification of everything <= thresh is exactly zero
+    const bool staged_tri = filter == 1 && tri_slab_candidate(P, L);
+    if (!skip_empty || !(fast_path_eligible(P, L) || staged_tri)) return;
     const int nx = res_dims_[0], ny = res_dims_[1], nz = res_dims_[2];
-    // a batch of 8 samples must stay within +-1 cell of its middle sample: bound the voxel
-    // advance per step on every voxel axis (|dir| <= 1)
-    float max_delta = 0.0f;
-    const bool swz = (u_.view_bottom == 1 || u_.view_top == 1);
-    const float vdim[3] = {(float)nx, swz ? (float)nz : (float)ny, swz ? (float)ny : (float)nz};   // voxel axis behind each box axis
-    for (int a = 0; a < 3; a++) max_delta = std::max(max_delta, P.step * vdim[a] / P.ext[a]);
-    if (!(4.0f * max_delta + 0.6f <= 8.0f)) return;
+    if (!staged_tri) {
+        // a batch of 8 samples must stay within +-1 cell of its middle sample: bound the voxel
+        // advance per step on every voxel axis (|dir| <= 1)
+        float max_delta = 0.0f;
+        const bool swz = (u_.view_bottom == 1 || u_.view_top == 1);
+        const float vdim[3] = {(float)nx, swz ? (float)nz : (float)ny, swz ? (float)ny : (float)nz};   // voxel axis behind each box axis
+        for (int a = 0; a < 3; a++) max_delta = std::max(max_delta, P.step * vdim[a] / P.ext[a]);
+        if (!(4.0f * max_delta + 0.6f <= 8.0f)) return;
+    }
     // threshold: largest voxel value whose classification is exactly zero
     int thresh;
     if (P.alpha_scale == 0.0f) {
@@ -1092,12 +1097,16 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
     } else {
         int e = 0;
         const int width = u_.max_val - u_.min_val;
+        // TRILINEAR classifies values BETWEEN the integers too: they reach every table entry up to the one of the largest tap
+        // (the index is monotone in the value), so there the whole leading run of entries has to be invisible
+        int zero_run = 0;
+        while (zero_run < 256 && tf_lut_[4 * zero_run + 3] * P.alpha_scale == 0.0f) zero_run++;
         for (; e <= width; e++) {
             const float s = (float)(u_.min_val + e);
             const float v = (s - P.fmin) / P.fden;       // == the kernel's certified quotient
             int idx = (int)std::floor(v * 255.0f + 0.5f);
             idx = std::min(std::max(idx, 0), 255);
-            if (tf_lut_[4 * idx + 3] * P.alpha_scale != 0.0f) break;
+            if (staged_tri ? idx >= zero_run : tf_lut_[4 * idx + 3] * P.alpha_scale != 0.0f) break;
         }
         thresh = u_.min_val + e - 1;                     // e == 0: even the lowest entry is visible
         if (e == 0) return;

@@ -108,7 +108,11 @@ struct TslabCfg {
 // layer thickness 4 or 2 per tile; otherwise the order-0 copy for every tile, pairs along x, whole layers
 // TW: wavefronts per tile row -- 4: 32x16-pixel tiles (32x32 with 16 wavefronts); 2: 16x32-pixel tiles, whose brick rectangles are
 // a fifth smaller where the view's shear runs along the image's x direction (views near a body diagonal of the volume)
-template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB, bool PERM, int TW = 4>
+// SKIP (round 5): exact empty-space skipping (vr_set_skip_empty; FrameParams::skip_empty / skip_thresh, the dilated cell-max grid of
+// the NEAREST kernels) at the granularity this kernel works in -- a tile's brick LAYER: a layer whose rectangle lies in cells that
+// classify to exactly (0,0,0,0) is not requested from HBM, and the phase that would sample it only steps the rays through it
+// (the shader's position additions, nothing else).  Frames and per-pixel sample counts are bit-identical with and without it.
+template <typename VoxelT, int DIVTC, int VIEW, bool POW2, int MODE, int NW, int LDSKB, bool PERM, int TW = 4, bool SKIP = false>
 __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, TW>::WAVES_PER_SIMD)) void raymarch_tslab_kernel(const FrameParams P,
                                                                        const VoxelT *__restrict__ vol,
                                                                        const uint8_t *__restrict__ src,
@@ -118,7 +122,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                                                                        float4 *__restrict__ fb,
                                                                        uint32_t *__restrict__ spp,
                                                                        const uint32_t *__restrict__ tile_table,
-                                                                       const int no_stage)
+                                                                       const int no_stage,
+                                                                       const uint16_t *__restrict__ skip_grid)
 {
     using C = TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, TW>;
     // rows (the ring's rows with their own brick ranges, below): compiled into the 16x32-pixel shapes only -- the views that need rows are
@@ -382,6 +387,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     bool use_strip = false, try_rows = false;
     float strip_k = 0.0f;
     int rowtab_off = 0;
+    // SKIP: one bit per planned layer in the plan entry's spare bits (29 of its first word: a brick index is below 2^13,
+    // vr_kernels.hip: tri_slab_candidate): the layer holds something visible (below)
+    const bool skip_on = SKIP && P.skip_empty != 0 && skip_grid != nullptr;
+    constexpr uint32_t LOB_MASK = SKIP ? 0x1fffu : 0xffffu;              // the entry's second 16-bit field
     // brick range [alo, alo + w) of brick row r of a layer whose band is c1 <= a + strip_k * b <= c2 inside bricks lo_a .. hi_a:
     // the taps of row r come from positions with b in [4 r - mrg, 4 r + 4 + mrg]
     auto strip_row = [&](float c1, float c2, int lo_a, int hi_a, int r, int &alo, int &w) {
@@ -617,9 +626,61 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                 ld_rel[q] = ((uint32_t)ta * sA + (uint32_t)tb * sB) * (uint32_t)C::BRICK_BYTES + (uint32_t)part * 16u;
             }
         }
+        if (skip_on) {
+            // ---- SKIP: which planned layers hold anything visible.  A sample of phase L has its base voxel (floor(f - 0.5) per
+            // axis) inside layer L's rectangle and inside the layer, i.e. in one of the 8^3-voxel cells (brick >> 1 along a and b,
+            // (T L) >> 3 along m) the rectangle touches; the grid holds every cell's maximum over the cell AND its 26 neighbours, so
+            // it bounds all eight taps (the + 1 neighbours may lie in the next cell).  An interpolated value never exceeds its largest
+            // tap (each lerp is one fma of values between its end points, rounding is monotone), so where every touched cell is
+            // <= skip_thresh (host: the largest voxel value that classifies to exactly zero, with everything below it) every sample
+            // of the phase adds exactly nothing.  One wavefront per four layers, a lane per cell; the four loads are in flight together.
+            __syncthreads();                                             // (the torus positions above were derived from the entries' first words)
+            const uint32_t cst1 = (uint32_t)P.cnx, cst2 = (uint32_t)P.cnx * (uint32_t)P.cny;
+            const uint32_t csA = sel3(ax_a, 1u, cst1, cst2), csB = sel3(ax_b, 1u, cst1, cst2), csM = sel3(ax_m, 1u, cst1, cst2);
+            for (int Lb = Llo + 4 * (int)wave; Lb <= Lhi; Lb += 4 * TS_NW) {
+                uint32_t vmax[4], cbase[4];
+                int nca[4], ncell[4];
+                float rn[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int L = min(Lb + u, Lhi);                      // (past the last layer: that layer again)
+                    const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
+                    const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+                    const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16), dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u);
+                    const int ca0 = lo_a >> 1, cb0 = lo_b >> 1;
+                    nca[u] = ((lo_a + dda) >> 1) - ca0 + 1;
+                    ncell[u] = nca[u] * (((lo_b + ddb) >> 1) - cb0 + 1);
+                    cbase[u] = (uint32_t)((T * L) >> 3) * csM + (uint32_t)ca0 * csA + (uint32_t)cb0 * csB;
+                    rn[u] = 1.0f / (float)nca[u];
+                }
+                auto cell_of = [&](int u, int c) -> uint32_t {       // c-th cell of layer u's rectangle, row-major (c < 2^16: the quotient is exact)
+                    const int cb = (int)(((float)c + 0.5f) * rn[u]), ca = c - cb * nca[u];
+                    return cbase[u] + (uint32_t)ca * csA + (uint32_t)cb * csB;
+                };
+#pragma unroll
+                for (int u = 0; u < 4; u++) vmax[u] = (int)lane < ncell[u] ? (uint32_t)skip_grid[cell_of(u, (int)lane)] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    for (int c = (int)lane + 64; c < ncell[u]; c += 64) vmax[u] = max(vmax[u], (uint32_t)skip_grid[cell_of(u, c)]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool visible = __any((int)vmax[u] > P.skip_thresh ? 1 : 0) != 0;
+                    if (visible && Lb + u <= Lhi && lane == 0) *reinterpret_cast<uint32_t *>(plan_b + (ptrdiff_t)(Lb + u) * plan_stride) |= 1u << 29;
+                }
+            }
+        }
     }
     __syncthreads();
     const uint32_t ring_base = lds_offset_of(slots);
+    // SKIP: does layer X hold anything visible (per lane; everything does without skipping) / is it read by a phase that samples --
+    // as its own layer, or as the layer of the + 1 taps of the one below
+    auto layer_visible = [&](int X) -> bool {
+        if (!skip_on) return true;
+        if (X < Llo || X > Lhi) return false;
+        return ((*reinterpret_cast<const uint32_t *>(plan_b + (ptrdiff_t)X * plan_stride) >> 29) & 1u) != 0u;
+    };
+    auto layer_needed_lane = [&](int X) -> bool { return layer_visible(X) || layer_visible(X - 1); };
+    auto layer_needed = [&](int X) -> bool { return !skip_on || __any(layer_needed_lane(X) ? 1 : 0) != 0; };   // (uniform X: the prologue's requests)
 
     // request the bricks of layer L (its rectangle of the plan) into slot L mod RZ.  Per lane and piece: two wrap-around tests
     // (is this lane's torus column / row below the rectangle's torus origin?), two extent tests, two masked adds -- the layer's
@@ -631,7 +692,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     auto make_rows = [&](int L) {
         if (L < Llo || L > Lhi) return;
         const uint4 e = *reinterpret_cast<const uint4 *>(plan_b + (ptrdiff_t)L * 16);
-        const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)(e.x >> 16), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u), la = (int)((e.y >> 16) & 255u);
+        const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)((e.x >> 16) & LOB_MASK), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u), la = (int)((e.y >> 16) & 255u);
         if ((int)lane <= ddb && lane < 32u) {
             int alo, w;
             strip_row(__uint_as_float(e.z), __uint_as_float(e.w), lo_a, lo_a + dda, lo_b + (int)lane, alo, w);
@@ -648,7 +709,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         if (L < Llo || L > Lhi) return;
         const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
         const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
-        const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16);
+        const int lo_a = (int)(ex & 0xffffu), lo_b = (int)((ex >> 16) & LOB_MASK);
         const int dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u), la = (int)((ey >> 16) & 255u), lb = (int)(ey >> 24);
         const int lz = L % RZ;
         // brick layer and, for half layers, which half of the brick (its first or last two planes along m: 40 contiguous voxels)
@@ -700,8 +761,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             if ((int)wave < LA + 2) make_rows(first + (int)wave);
             __syncthreads();
         }
-        if (sgn > 0) { for (int l = 0; l <= LA; l++) issue_layer(L0 + l); }
-        else { for (int l = 1; l >= 1 - LA; l--) issue_layer(L0 + l); }
+        if (sgn > 0) { for (int l = 0; l <= LA; l++) if (layer_needed(L0 + l)) issue_layer(L0 + l); }
+        else { for (int l = 1; l >= 1 - LA; l--) if (layer_needed(L0 + l)) issue_layer(L0 + l); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // prepared sample (the one at the current position): tap BYTE addresses of the four corner pairs -- (O1, O2) = (0,0),
@@ -748,7 +809,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     const int lo_res = sgn > 0 ? L : L - (LA >= 2 ? 1 : 0), hi_res = sgn > 0 ? L + 1 + (LA >= 2 ? 1 : 0) : L + 1;
                     if (lyr < lo_res || lyr > hi_res || lyr < Llo || lyr > Lhi) { bad++; continue; }
                     const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)lyr * plan_stride);
-                    const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)(e.x >> 16), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u);
+                    const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)((e.x >> 16) & LOB_MASK), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u);
                     const int ba = ia >> 2, bb = jb >> 2;
                     if (ba < lo_a || ba > lo_a + dda || bb < lo_b || bb > lo_b + ddb) { bad++; continue; }
                     if (ROWS && use_strip) {                             // rows: inside the row's own range (what make_rows had loaded)
@@ -791,10 +852,69 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         const bool ahead_ok = LA >= 2;
         float takenf = 0.0f;
         const float limitf = (float)rem;
-        for (int p = 0; p < n_phases; p++) {
+        // SKIP: the phases come in RUNS -- stretches of layers with something visible, marched by the phase loop as it is without
+        // skipping (requests included: at most LA + 1 layers per run are fetched for nothing), and stretches of empty layers, which
+        // the rays cross in ONE loop of position additions behind which only the layers the next sampling phases read are requested.
+        // (Two kinds of phase inside one loop cost every sampling phase 15 %: with a second sample loop next to it the register
+        // allocator puts the loop-carried values of the first back into other registers between the phases -- measured, 1.09 ->
+        // 1.26 ms with nothing to skip; as runs those copies happen once per run.)
+        auto request_of = [&](int q) -> int { const int Lq = L0 + sgn * q; return sgn > 0 ? Lq + LA + 1 : Lq - LA; };   // the layer phase q requests
+        bool tile_done = false;
+        for (int p = 0; p < n_phases && !tile_done;) {
+            int p_end = n_phases;                                        // end of the run that starts at phase p
+            bool sampling = true;
+            if (SKIP && skip_on) {
+                // the next 64 phases' layers at once: a lane each
+                const int q = p + (int)lane;
+                const uint64_t vm = __ballot((q < n_phases && layer_visible(L0 + sgn * q)) ? 1 : 0);
+                sampling = (vm & 1ull) != 0ull;
+                const uint64_t change = sampling ? ~vm : vm;             // (phases beyond the last count as empty)
+                p_end = min(p + (change != 0ull ? (int)__builtin_ctzll(change) : 64), n_phases);
+            }
+            if (SKIP && !sampling) {
+                const int run = p_end - p;
+                // the requests of the run's phases that a sampling phase behind the run reads (at most LA + 1 layers, consecutive)
+                const int ql = p + (int)lane;
+                uint64_t need = __ballot(((int)lane < run && layer_needed_lane(request_of(ql))) ? 1 : 0);
+                if (ROWS && use_strip) {                                 // rows: their tables first, a wavefront each
+                    uint64_t nm = need;
+                    for (int w = 0; nm != 0ull; w++, nm &= nm - 1ull)
+                        if ((int)wave == w) make_rows(request_of(p + (int)__builtin_ctzll(nm)));
+                    __syncthreads();
+                }
+                for (; need != 0ull; need &= need - 1ull) issue_layer(request_of(p + (int)__builtin_ctzll(need)));
+                if (ROWS && use_strip && (int)wave == TS_NW - 1) make_rows(request_of(p_end));   // ... and of the layer the phase behind the run requests
+                // the rays: position additions until they stand in the first layer behind the run (or have no prefix sample left);
+                // a position's layer needs its major coordinate alone, and the sample a ray stops at is prepared once, behind the loop
+                const int lim = L0 + sgn * p_end + LAY_BIAS, sm = sgn >> 31;
+                const bool marching = da < 0.95f;                        // (dest.a does not change in here)
+                bool here = marching && takenf < limitf && (((lay - lim) ^ sm) - sm) < 0;
+                if (__any(here ? 1 : 0)) {
+                    do {
+                        const float vf = here ? 1.0f : 0.0f;
+                        if (POW2) { Qx = __builtin_fmaf(dSx, vf, Qx); Qy = __builtin_fmaf(dSy, vf, Qy); Qz = __builtin_fmaf(dSz, vf, Qz); }
+                        else { qx = __builtin_fmaf(dsx, vf, qx); qy = __builtin_fmaf(dsy, vf, qy); qz = __builtin_fmaf(dsz, vf, qz); }
+                        takenf += vf;
+                        float fx, fy, fz;
+                        scaled_here(fx, fy, fz);
+                        const float tm = __builtin_truncf((M == 0 ? fx : (M == 1 ? fy : fz)) - 0.5f);
+                        lay = (int)(__float_as_uint(__builtin_fmaf(tm, 4.0f, k_magic)) >> (2 + LSH));
+                        VR_TSLAB_STAT(st_iters++;)
+                        here = marching && takenf < limitf && (((lay - lim) ^ sm) - sm) < 0;
+                    } while (__any(here ? 1 : 0));
+                    prepare(); weights();
+                }
+                slab_wait_pieces(0);
+                if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) tile_done = true;
+                p = p_end;
+                continue;
+            }
+            for (; p < p_end; p++) {
             const int L = L0 + sgn * p, Lnext = L + sgn;
             // the layer that phase p + LA reads first
             issue_layer(sgn > 0 ? L + LA + 1 : L - LA);
+            // (SKIP: no running ahead out of a run -- the layer behind it is not sampled and may not have been requested)
+            const bool ahead_p = SKIP ? (ahead_ok && p + 1 < p_end) : ahead_ok;
             if (ROWS && use_strip && (int)wave == (p & (TS_NW - 1))) make_rows(sgn > 0 ? L + LA + 2 : L - LA - 1);   // rows: the table of the layer the NEXT phase requests
             // ---- this phase's samples: the ones whose cell lies in layer L.  The body is straight-line code for the whole
             // wavefront: a lane without a sample in this layer reads taps at its (valid, unchanged) prepared addresses and
@@ -824,7 +944,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     // idle slot of the iteration that the 5-sample lanes need, and own a sample less in the next phase -- the
                     // wavefront then takes ~4.1 iterations per layer instead of max(4, 5) = 5.  The phase still ends when no lane is
                     // left IN layer L.
-                    const bool valid = here || (alive && lay == Lnext + LAY_BIAS && ahead_ok);
+                    const bool valid = here || (alive && lay == Lnext + LAY_BIAS && ahead_p);
                     VR_TSLAB_STAT(st_iters++; st_samples += valid ? 1 : 0;)
                     VR_TSLAB_CHK(if (valid) chk_violations += check_taps(L);)
                     const float vf = valid ? 1.0f : 0.0f;
@@ -887,8 +1007,9 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // that is the layer just requested, with two it was requested a phase ago
             slab_wait_pieces(0);                                         // (with two phases of distance the extra layer serves the rays that run ahead)
             // every 8th phase the barrier doubles as the vote "no ray of the tile has prefix samples left"
-            if ((p & 7) == 7) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) break; }
+            if ((p & 7) == 7) { if (__syncthreads_and(!(takenf < limitf && da < 0.95f) ? 1 : 0)) { tile_done = true; break; } }
             else __syncthreads();
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // no DMA may outlive the workgroup's LDS
         i += (int)takenf;
@@ -1015,19 +1136,30 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
 
 // ------------------------------------------------------------------ dispatch
 // One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4 / 6: u8; 1 .. 3, 5: u16 (below)
-template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
-static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
-                               uint32_t *spp, hipStream_t st)
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE, bool SKIP>
+static hipError_t launch_tslab2(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                                uint32_t *spp, hipStream_t st)
 {
     static_assert(NW == 8, "tile tables exist for 8-wavefront tiles");
     const uint32_t *table = TW == 2 ? L.tile_table_tall : L.tile_table;
     const uint32_t blocks = TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks;
     int no_stage = L.tri_slab == 2 ? 1 : 0;
     VR_TSLAB_CHK(if (std::getenv("VR_TSLAB_SABOTAGE") != nullptr) no_stage = 3;)   // checked build only: the plan guard's negative control
-    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM, TW>), dim3(blocks), dim3(64 * NW), 0, st, P,
+    hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM, TW, SKIP>), dim3(blocks), dim3(64 * NW), 0, st, P,
                        (const VoxelT *)vol, (const uint8_t *)L.apron, (const uint8_t *)L.apron_y, (const uint8_t *)L.apron_x, tf, fb, spp, table,
-                       no_stage);
+                       no_stage, SKIP ? L.skip_grid : nullptr);
     return hipGetLastError();
+}
+
+// the SKIP instances run only the launches that asked for empty-space skipping (host: refreshSkipGrid): every other launch
+// keeps the phase loop without the layer flags
+template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE>
+static hipError_t launch_tslab(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
+                               uint32_t *spp, hipStream_t st)
+{
+    if (P.skip_empty != 0 && L.skip_grid != nullptr)
+        return launch_tslab2<VoxelT, NW, LDSKB, PERM, TW, DIVTC, VIEW, POW2, MODE, true>(P, L, vol, tf, fb, spp, st);
+    return launch_tslab2<VoxelT, NW, LDSKB, PERM, TW, DIVTC, VIEW, POW2, MODE, false>(P, L, vol, tf, fb, spp, st);
 }
 
 template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int VIEW, int MODE>
