@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """experiment (needs a stats build of vr_tslab.hip: make TSLAB_TAG=_st TSLAB_DEFS="-DVR_EXPERIMENTS -DVR_X_STATS", then
 VR_CORE_LIB=.../libvr_core_st.so): per-tile load-plan statistics of the LDS-staged TRILINEAR kernel on the bench workload.
-  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale] [kernel variant: 6, 8, 9]"""
+  tools/tslab_stats.py [default|offaxis|zenith,azimuth] [N] [bytes] [alpha_scale] [kernel variant: 6, 8, 9] [window low: > 0 switches empty-space skipping on]"""
 import importlib, sys
 from pathlib import Path
 import numpy as np
@@ -21,6 +21,8 @@ if pose == "offaxis":
 elif "," in pose:                       # "zenith,azimuth" as passed to cameraOrient
     r.cameraOrient(0.0, *[float(v) for v in pose.split(",")])
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 6
+if len(sys.argv) > 6 and int(sys.argv[6]) > 0:
+    r.setWindow(int(sys.argv[6]), 4095 if b == 2 else 255); r.setSkipEmpty(True)
 TH, TWP = (32, 16) if variant == 9 else (16, 32)              # rows per tile
 r.setKernelVariant(variant)
 r.render()
@@ -36,6 +38,9 @@ print(f"tiles with a prefix {m.sum()} of {st.size}; staged {int(staged.sum())} (
       f"RA*RB of unstaged tiles: percentiles 10/50/90/100 {np.percentile(slots[staged == 0], [10, 50, 90, 100]) if (staged == 0).any() else None} (255 = 255 or more, or not computed); phases mean {phases.mean():.1f} max {phases.max()}")
 clk, wall, iters, samp = spp[::TH, 1::TWP][m].astype(np.float64), spp[::TH, 2::TWP][m].astype(np.float64), spp[::TH, 3::TWP][m].astype(np.float64), spp[::TH, 4::TWP][m].astype(np.float64)
 setup = spp[::TH, 5::TWP][m].astype(np.float64)
+skipw = spp[::TH, 6::TWP][m]
+skipped, runs = (skipw & 0xffff).astype(np.float64), (skipw >> 16).astype(np.float64)
+print(f"empty-space skipping: {skipped.sum():.0f} of {phases.sum():.0f} phases crossed in {runs.sum():.0f} empty runs ({skipped.sum() / max(phases.sum(), 1):.3f}); tiles with no sampled phase {(skipped >= phases).sum()}")
 ok = wall > 0
 print(f"set-up before the march (ray, checked head, load plan, tables): mean {setup[ok].mean():.0f} ticks = {100 * setup[ok].sum() / (setup[ok].sum() + clk[ok].sum()):.1f} % of the tiles' time")
 for flag, name in ((1, "staged"), (0, "not staged")):

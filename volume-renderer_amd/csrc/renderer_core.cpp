@@ -49,6 +49,7 @@ RendererCore::~RendererCore()
         if (d_tf_) (void)hipFree(d_tf_);
         if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
+        if (d_tile_work_) (void)hipFree(d_tile_work_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
@@ -210,6 +211,7 @@ void RendererCore::freeVolume()
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
     res_dims_[0] = res_dims_[1] = res_dims_[2] = 0; res_bytes_ = 0;
     if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
+    if (tile_table_skip_sig_ != 0) tile_table_skip_sig_ = -1;            // (an order built on the old volume's visibility)
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
     vol12_failed_ = false;
     if (d_apron_) { (void)hipFree(d_apron_); d_apron_ = nullptr; apron_bytes_ = 0; }
@@ -1060,7 +1062,7 @@ void RendererCore::residentBytes(uint64_t &volume, uint64_t &copies, uint64_t &o
     const uint64_t px = (uint64_t)framebuffer_size[0] * (uint64_t)framebuffer_size[1];
     other = (d_fb_ ? px * 16 : 0) + (d_tf_ ? 256 * 16 : 0) + (uint64_t)spp_capacity_ * 4 + (d_scratch_ ? 264 * 4 : 0) +
             (d_skip_grid_ ? (uint64_t)skip_grid_cells_ * 2 : 0) + (uint64_t)rgba8_capacity_ + (uint64_t)present_capacity_ * kPresentSlots +
-            ((uint64_t)tile_table_capacity_ + (uint64_t)tile_table_tall_capacity_) * 4;
+            ((uint64_t)tile_table_capacity_ + (uint64_t)tile_table_tall_capacity_ + (uint64_t)tile_work_capacity_) * 4;
 }
 
 // Exact empty-space skipping (vr_set_skip_empty): the fast kernel may skip a batch of
@@ -1153,9 +1155,37 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
     const bool need32 = filter == 1 && tri_slab_candidate(P, L) && (P.stripe_count <= 1 || P.stripe_rows % 32 == 0 || force_generic == 9);   // 16x32-pixel tiles for the staged trilinear kernel's tall shape
-    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0)) {
+    // empty-space skipping: the order follows the tiles' VISIBLE work (vr_kernels.hip: tile_visible_work_kernel); it changes with
+    // the threshold (window / transfer function), not only with the camera
+    // (NEAREST skips per ray and batch: every pose.  The staged TRILINEAR kernel skips per tile and brick layer, and its tiles
+    // that do not fit the ring skip nothing: where the view is oblique the estimate misjudges exactly the longest tiles -- the
+    // off-axis pose ran 1.46 / 1.55 / 2.2 ms depending on where they landed -- so there the order stays the geometric one)
+    const bool skip_order = P.skip_empty != 0 && L.skip_grid != nullptr && (filter == 0 || viewAxisAlignment(P) >= 0.92);
+    const int64_t skip_sig = skip_order ? (int64_t)P.skip_thresh + 1 : 0;
+    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0) || skip_sig != tile_table_skip_sig_) {
         std::vector<uint32_t> table;
-        tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_);
+        std::vector<float> work, work_tall;
+        if (skip_order) {
+            // (one small kernel and a synchronous copy per table, only when the table is rebuilt; an empty sample costs about
+            // a seventh of a sampled one in both kernel families)
+            auto estimate = [&](unsigned tw, unsigned th, std::vector<float> &out) {
+                const size_t n = (size_t)((P.img_w + (int)tw - 1) / (int)tw) * (size_t)((rows + (int)th - 1) / (int)th);
+                if (2 * n > tile_work_capacity_) {
+                    if (d_tile_work_) { check(hipFree(d_tile_work_), "hipFree(tile work)"); d_tile_work_ = nullptr; }
+                    check(hipMalloc(reinterpret_cast<void **>(&d_tile_work_), 2 * n * sizeof(float)), "hipMalloc(tile work)");
+                    tile_work_capacity_ = 2 * n;
+                }
+                check(launch_tile_visible_work(P, L.skip_grid, rows, tw, th, 0.15f, filter == 1 ? 1 : 0, d_tile_work_, stream()), "tile_visible_work_kernel");
+                std::vector<float> both(2 * n);
+                check(hipMemcpyAsync(both.data(), d_tile_work_, 2 * n * sizeof(float), hipMemcpyDeviceToHost, stream()), "hipMemcpy(tile work)");
+                check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+                out.resize(n);
+                for (size_t t = 0; t < n; t++) out[t] = both[2 * t + 1] > 0.0f ? std::min(both[2 * t] / both[2 * t + 1], 1.0f) : 1.0f;   // cost with skipping / without
+            };
+            estimate(kFastTileW, kFastTileH, work);
+            if (need32) estimate(16u, 32u, work_tall);
+        }
+        tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_, kFastTileH, kFastTileW, skip_order ? work.data() : nullptr);
         // synchronous copies: the tables are pageable temporaries
         check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
         auto upload = [&](uint32_t *&d, size_t &capacity, size_t &blocks, const std::vector<uint32_t> &t) {
@@ -1171,10 +1201,11 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
         tile_table_tall_blocks_ = 0;
         if (need32) {
             std::vector<uint32_t> tall;
-            (void)buildTileSchedule(P, rows, tall, nullptr, 32u, 16u);
+            (void)buildTileSchedule(P, rows, tall, nullptr, 32u, 16u, skip_order ? work_tall.data() : nullptr);
             upload(d_tile_table_tall_, tile_table_tall_capacity_, tile_table_tall_blocks_, tall);
         }
         tile_table_key_ = shape_key;
+        tile_table_skip_sig_ = skip_sig;
         std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
     }
     L.tile_table = d_tile_table_;

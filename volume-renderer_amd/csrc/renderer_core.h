@@ -190,6 +190,9 @@ private:
     uint32_t *d_tile_table_tall_ = nullptr;  // the same for 16x32-pixel tiles (the staged trilinear kernel's tall shape); built with the table above
     size_t tile_table_tall_capacity_ = 0, tile_table_tall_blocks_ = 0;
     uint64_t tile_table_key_ = 0;
+    int64_t tile_table_skip_sig_ = 0;        // what the order was built for: 0 = geometric ray lengths, threshold + 1 = visible work under empty-space skipping (-1: rebuild)
+    float *d_tile_work_ = nullptr;           // per-tile cost estimates of that (scratch of refreshTileSchedule)
+    size_t tile_work_capacity_ = 0;
     float tile_table_cam_[21] = {};          // camera block the cached order was built for
     unsigned tile_active_ = 0;               // tiles with work in the cached schedule
     double tile_longest_ = 0.0;              // expected samples of its longest ray

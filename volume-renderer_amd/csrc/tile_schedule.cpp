@@ -100,7 +100,8 @@ uint64_t tileScheduleKey(const FrameParams &P, int rows, bool with_camera)
     return hsh;
 }
 
-unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples, unsigned tile_h, unsigned tile_w)
+unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples, unsigned tile_h, unsigned tile_w,
+                           const float *work_override)
 {
     unsigned active_tiles = 0;
     double longest = 0.0;
@@ -129,7 +130,8 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
                     const double py = std::min((double)pr[r], (double)P.img_h - 1.0) + 0.5;
                     wmax = std::max(wmax, raySamples(P, px, py));
                 }
-            tile_work[(size_t)ty * tiles_x + tx] = wmax;
+            // (a tile the geometric estimate calls active keeps a non-zero cost: the table's padding logic is about WHICH tiles exist)
+            tile_work[(size_t)ty * tiles_x + tx] = (work_override && wmax > 0.0) ? std::max(wmax * (double)work_override[(size_t)ty * tiles_x + tx], 1.0e-3) : wmax;
             if (wmax > 0.0) active_tiles++;
             longest = std::max(longest, wmax);
         }

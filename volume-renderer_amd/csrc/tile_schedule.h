@@ -23,8 +23,10 @@ constexpr uint32_t kTilePadding = 0xffffffffu;
 // returns the number of tiles with a non-zero work estimate (*max_ray_samples: the longest ray's expected sample count)
 // tile_h / tile_w: rows / columns per tile (kFastTileH x kFastTileW; the staged trilinear kernel also runs 32x32-pixel tiles on
 // 16-wavefront workgroups and 16x32-pixel ones)
+// work_scale (tiles_x * tiles_y floats in (0, 1], row-major; nullptr = none): the ORDER follows the geometric ray lengths times
+// these -- empty-space skipping, where a tile's cost is its rays' visible stretch (vr_kernels.hip: tile_visible_work_kernel)
 unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t> &table, double *max_ray_samples = nullptr, unsigned tile_h = kFastTileH,
-                           unsigned tile_w = kFastTileW);
+                           unsigned tile_w = kFastTileW, const float *work_override = nullptr);
 
 // how close the view is to a volume axis: |largest component| of the central ray's direction in voxel units, 1 = along
 // an axis, 0.58 = along the space diagonal.  Launch heuristics only (RendererCore::prepareLaunch).

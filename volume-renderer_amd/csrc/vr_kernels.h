@@ -30,6 +30,13 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
 hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
                                   uint32_t bnx, uint32_t bny, uint16_t *tmp, uint16_t *out, hipStream_t st);
 
+// expected cost per tile under empty-space skipping (a scheduling estimate: visible stretch + empty_cost x empty stretch of the
+// longest of nine probe rays); work[2 * tiles_x * tiles_y] floats: per tile the cost with skipping and the cost without it (0, 0 = no
+// probe ray enters the box) -- the caller scales its own geometric estimate by their ratio
+// per_layer: the LDS-staged TRILINEAR kernel's granularity (a tile's brick layer is skipped when NO probe ray touches anything visible in it)
+hipError_t launch_tile_visible_work(const FrameParams &P, const uint16_t *grid, int rows, unsigned tile_w, unsigned tile_h, float empty_cost,
+                                    int per_layer, float *work, hipStream_t st);
+
 // *d_bad must be zeroed by the caller; non-zero afterwards = divisor not certified
 hipError_t launch_certify_div(float b, float r, unsigned *d_bad, hipStream_t st);
 

@@ -1921,6 +1921,135 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
     return hipGetLastError();
 }
 
+// Expected cost of every tile under empty-space skipping (host: refreshTileSchedule).  The tile order is longest-first by the
+// tiles' expected ray lengths (tile_schedule.cpp); with skipping a ray's cost is the length of its VISIBLE stretch plus a small
+// share of the empty one, and a frame is only two or three rounds of tiles, so the order must know it: tiles through the
+// ball's centre first, not the ones that cross the cube's empty corners (cfg3 windowed, TRILINEAR: the frame ended 0.3 ms after
+// the work was done, waiting for full-length tiles that had started last).  One thread per (tile, probe pixel): the same nine
+// probe pixels as the host's estimate, 128 equidistant probes of the dilated cell-max grid along the ray's stretch in the box.
+// An ESTIMATE: positions go through the affine map, not the shader's divisions; the image never depends on it.
+__global__ __launch_bounds__(256) void tile_visible_work_kernel(const FrameParams P, const uint16_t *__restrict__ grid, int rows, unsigned tiles_x,
+                                                                unsigned tiles_y, unsigned tile_w, unsigned tile_h, float empty_cost,
+                                                                unsigned *__restrict__ work)
+{
+    const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tile = id / 9u, probe = id % 9u;
+    if (tile >= tiles_x * tiles_y) return;
+    const unsigned tx = tile % tiles_x, ty = tile / tiles_x;
+    const int lx = min((int)(tx * tile_w + (probe % 3u) * (tile_w - 1u) / 2u), P.img_w - 1);
+    int ly = (int)(ty * tile_h + (probe / 3u) * (tile_h - 1u) / 2u);
+    ly = min(ly, rows - 1);
+    int py;
+    if (P.stripe_count > 1) {
+        const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
+        py = (st * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+    } else {
+        py = P.row_begin + ly;
+    }
+    py = min(py, P.img_h - 1);
+    const Ray ray = compute_ray(P, (float)lx + 0.5f, (float)py + 0.5f);
+    float t_min = 0.0f, t_max = 0.0f;
+    if (!intersect_ray_aabb(P, ray, t_min, t_max)) return;
+    const float len = fminf((t_max - t_min) / P.step, (float)P.max_steps);
+    constexpr int K = 128;
+    int visible = 0;
+    for (int k = 0; k < K; k++) {
+        const float t = t_min + (t_max - t_min) * (((float)k + 0.5f) / (float)K);
+        const float ax = ray.ox + ray.dx * t, ay = ray.oy + ray.dy * t, az = ray.oz + ray.dz * t;
+        const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
+        const float uzr = (az + P.half[2]) * P.rext[2], uz = 1.0f - uzr;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (P.view_top == 1) { tcy = uzr; tcz = uy; }
+        else if (P.view_bottom == 1) { tcy = uz; tcz = 1.0f - uy; }
+        const int ci = min(max((int)(tcx * P.fdim[0]) >> 3, 0), P.cnx - 1), cj = min(max((int)(tcy * P.fdim[1]) >> 3, 0), P.cny - 1);
+        const int ck = min(max((int)(tcz * P.fdim[2]) >> 3, 0), P.cnz - 1);
+        visible += (int)grid[((size_t)ck * (size_t)P.cny + (size_t)cj) * (size_t)P.cnx + (size_t)ci] > P.skip_thresh ? 1 : 0;
+    }
+    const float f = (float)visible / (float)K;
+    const float w = fmaxf(len * (f + (1.0f - f) * empty_cost), 1.0e-3f);
+    atomicMax(&work[2u * tile], __float_as_uint(w));                     // (positive floats order like their bit patterns)
+    atomicMax(&work[2u * tile + 1u], __float_as_uint(fmaxf(len, 1.0e-3f)));
+}
+
+// The same for the LDS-staged TRILINEAR kernel, which skips a tile's brick LAYER only when no ray of the tile touches anything
+// visible in it (vr_tslab.hip: SKIP): one thread per (tile, cell layer along the tile's major axis); the layer counts as sampled
+// when any of the nine probe rays stands in a visible cell where it crosses the layer's middle plane, as crossed when they are all in
+// empty ones, and not at all where no probe ray is inside the box.  (With per-ray visibility the order was right for views along an axis and wrong for
+// oblique ones, whose slanted layers mostly touch the ball somewhere: 1.46 -> 2.18 ms at the off-axis pose.)
+__global__ __launch_bounds__(256) void tile_layer_work_kernel(const FrameParams P, const uint16_t *__restrict__ grid, int rows, unsigned tiles_x,
+                                                              unsigned tiles_y, unsigned tile_w, unsigned tile_h, float empty_cost, unsigned kmax,
+                                                              float *__restrict__ work)
+{
+    const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned tile = id / kmax, j = id % kmax;
+    if (tile >= tiles_x * tiles_y) return;
+    const unsigned tx = tile % tiles_x, ty = tile / tiles_x;
+    auto to_voxel = [&](float ax, float ay, float az, float (&v)[3]) {
+        const float ux = (ax + P.half[0]) * P.rext[0], uy = (ay + P.half[1]) * P.rext[1];
+        const float uzr = (az + P.half[2]) * P.rext[2], uz = 1.0f - uzr;
+        float tcx = ux, tcy = uy, tcz = uz;
+        if (P.view_top == 1) { tcy = uzr; tcz = uy; }
+        else if (P.view_bottom == 1) { tcy = uz; tcz = 1.0f - uy; }
+        v[0] = tcx * P.fdim[0]; v[1] = tcy * P.fdim[1]; v[2] = tcz * P.fdim[2];
+    };
+    int m = 2;
+    bool in_box = false, visible = false;
+    const int cn[3] = {P.cnx, P.cny, P.cnz};
+    // (probe 4, the tile's central pixel, first: it names the major axis)
+    for (unsigned q = 0; q < 9u; q++) {
+        const unsigned probe = q == 0u ? 4u : (q <= 4u ? q - 1u : q);
+        const int lx = min((int)(tx * tile_w + (probe % 3u) * (tile_w - 1u) / 2u), P.img_w - 1);
+        const int ly = min((int)(ty * tile_h + (probe / 3u) * (tile_h - 1u) / 2u), rows - 1);
+        int py;
+        if (P.stripe_count > 1) {
+            const int st = ly / P.stripe_rows, r = ly % P.stripe_rows;
+            py = (st * P.stripe_count + P.stripe_index) * P.stripe_rows + r;
+        } else {
+            py = P.row_begin + ly;
+        }
+        py = min(py, P.img_h - 1);
+        const Ray ray = compute_ray(P, (float)lx + 0.5f, (float)py + 0.5f);
+        float E[3], F[3];
+        to_voxel(ray.ox, ray.oy, ray.oz, E);
+        to_voxel(ray.ox + ray.dx, ray.oy + ray.dy, ray.oz + ray.dz, F);
+        const float G[3] = {F[0] - E[0], F[1] - E[1], F[2] - E[2]};
+        if (q == 0u) {
+            const float g0 = fabsf(G[0]), g1 = fabsf(G[1]), g2 = fabsf(G[2]);
+            m = (g0 >= g1 && g0 >= g2) ? 0 : (g1 >= g2 ? 1 : 2);
+            if ((int)j >= cn[m]) return;
+        }
+        float t_min = 0.0f, t_max = 0.0f;
+        if (!intersect_ray_aabb(P, ray, t_min, t_max)) continue;
+        if (!(fabsf(G[m]) > 1.0e-6f)) continue;
+        const float t = ((float)(8u * j + 4u) - E[m]) / G[m];
+        if (!(t >= t_min && t <= t_max)) continue;
+        in_box = true;
+        const int ci = min(max((int)(E[0] + t * G[0]) >> 3, 0), P.cnx - 1), cj = min(max((int)(E[1] + t * G[1]) >> 3, 0), P.cny - 1);
+        const int ck = min(max((int)(E[2] + t * G[2]) >> 3, 0), P.cnz - 1);
+        visible = visible || (int)grid[((size_t)ck * (size_t)P.cny + (size_t)cj) * (size_t)P.cnx + (size_t)ci] > P.skip_thresh;
+    }
+    if (in_box) { atomicAdd(&work[2u * tile], visible ? 1.0f : empty_cost); atomicAdd(&work[2u * tile + 1u], 1.0f); }
+}
+
+hipError_t launch_tile_visible_work(const FrameParams &P, const uint16_t *grid, int rows, unsigned tile_w, unsigned tile_h, float empty_cost,
+                                    int per_layer, float *work, hipStream_t st)
+{
+    const unsigned tiles_x = (unsigned)((P.img_w + (int)tile_w - 1) / (int)tile_w), tiles_y = (unsigned)((rows + (int)tile_h - 1) / (int)tile_h);
+    const unsigned n = tiles_x * tiles_y;
+    hipError_t e = hipMemsetAsync(work, 0, (size_t)n * 2u * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    if (per_layer) {
+        const unsigned kmax = (unsigned)std::max(P.cnx, std::max(P.cny, P.cnz));
+        const uint64_t threads = (uint64_t)n * kmax;
+        hipLaunchKernelGGL(tile_layer_work_kernel, dim3((unsigned)((threads + 255u) / 256u)), dim3(256), 0, st, P, grid, rows, tiles_x, tiles_y, tile_w, tile_h,
+                           empty_cost, kmax, work);
+    } else {
+        hipLaunchKernelGGL(tile_visible_work_kernel, dim3((n * 9u + 255u) / 256u), dim3(256), 0, st, P, grid, rows, tiles_x, tiles_y, tile_w, tile_h,
+                           empty_cost, reinterpret_cast<unsigned *>(work));
+    }
+    return hipGetLastError();
+}
+
 // 12-bit packed copy of a u16 volume whose voxels are all <= 4095: voxel with storage index s
 // occupies bits [12s, 12s + 12) of a little-endian bit stream (8 voxels -> 3 dwords).  Any
 // the resident volume (linear or cube-bricked) -> TRILINEAR's apron copy (vr_device.h: build_axis_tables_apron)

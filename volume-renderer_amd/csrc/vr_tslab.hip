@@ -633,39 +633,48 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // it bounds all eight taps (the + 1 neighbours may lie in the next cell).  An interpolated value never exceeds its largest
             // tap (each lerp is one fma of values between its end points, rounding is monotone), so where every touched cell is
             // <= skip_thresh (host: the largest voxel value that classifies to exactly zero, with everything below it) every sample
-            // of the phase adds exactly nothing.  One wavefront per four layers, a lane per cell; the four loads are in flight together.
+            // of the phase adds exactly nothing.  A lane per cell, eight cell layers per wavefront with their loads in flight together.
             __syncthreads();                                             // (the torus positions above were derived from the entries' first words)
             const uint32_t cst1 = (uint32_t)P.cnx, cst2 = (uint32_t)P.cnx * (uint32_t)P.cny;
             const uint32_t csA = sel3(ax_a, 1u, cst1, cst2), csB = sel3(ax_b, 1u, cst1, cst2), csM = sel3(ax_m, 1u, cst1, cst2);
-            for (int Lb = Llo + 4 * (int)wave; Lb <= Lhi; Lb += 4 * TS_NW) {
-                uint32_t vmax[4], cbase[4];
-                int nca[4], ncell[4];
-                float rn[4];
+            // (layers of one cell layer -- two whole, four half layers -- are tested together, on the union of their rectangles)
+            const int GL = 3 - LSH, G = 1 << GL;                         // layers per cell layer
+            const int g_lo = Llo >> GL, g_hi = Lhi >> GL;
+            constexpr int SU = 8;                                        // cell layers per wavefront and round: eight loads in flight per lane
+            for (int gb = g_lo + SU * (int)wave; gb <= g_hi; gb += SU * TS_NW) {
+                uint32_t vmax[SU];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int L = min(Lb + u, Lhi);                      // (past the last layer: that layer again)
-                    const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
-                    const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
-                    const int lo_a = (int)(ex & 0xffffu), lo_b = (int)(ex >> 16), dda = (int)(ey & 255u), ddb = (int)((ey >> 8) & 255u);
-                    const int ca0 = lo_a >> 1, cb0 = lo_b >> 1;
-                    nca[u] = ((lo_a + dda) >> 1) - ca0 + 1;
-                    ncell[u] = nca[u] * (((lo_b + ddb) >> 1) - cb0 + 1);
-                    cbase[u] = (uint32_t)((T * L) >> 3) * csM + (uint32_t)ca0 * csA + (uint32_t)cb0 * csB;
-                    rn[u] = 1.0f / (float)nca[u];
+                for (int u = 0; u < SU; u++) {
+                    const int g = gb + u;
+                    int lo_a = 0x7fffffff, hi_a = -1, lo_b = 0x7fffffff, hi_b = -1;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int L = (g << GL) + k;
+                        if (k < G && g <= g_hi && L >= Llo && L <= Lhi) {
+                            const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
+                            const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+                            const int la_ = (int)(ex & 0xffffu), lb_ = (int)((ex >> 16) & LOB_MASK);
+                            lo_a = min(lo_a, la_); hi_a = max(hi_a, la_ + (int)(ey & 255u));
+                            lo_b = min(lo_b, lb_); hi_b = max(hi_b, lb_ + (int)((ey >> 8) & 255u));
+                        }
+                    }
+                    const int ca0 = lo_a >> 1, cb0 = lo_b >> 1, nca = (hi_a >> 1) - ca0 + 1;
+                    const int ncell = hi_a < 0 ? 0 : nca * ((hi_b >> 1) - cb0 + 1);
+                    const uint32_t cbase = (uint32_t)g * csM + (uint32_t)ca0 * csA + (uint32_t)cb0 * csB;
+                    const float rn = 1.0f / (float)nca;
+                    auto cell_of = [&](int c) -> uint32_t {              // c-th cell of the rectangle, row-major (c < 2^16: the quotient is exact)
+                        const int cb = (int)(((float)c + 0.5f) * rn), ca = c - cb * nca;
+                        return cbase + (uint32_t)ca * csA + (uint32_t)cb * csB;
+                    };
+                    vmax[u] = (int)lane < ncell ? (uint32_t)skip_grid[cell_of((int)lane)] : 0u;
+                    if (ncell > 64)                                      // (wide rectangles: the rows of the tall tiles)
+                        for (int c = (int)lane + 64; c < ncell; c += 64) vmax[u] = max(vmax[u], (uint32_t)skip_grid[cell_of(c)]);
                 }
-                auto cell_of = [&](int u, int c) -> uint32_t {       // c-th cell of layer u's rectangle, row-major (c < 2^16: the quotient is exact)
-                    const int cb = (int)(((float)c + 0.5f) * rn[u]), ca = c - cb * nca[u];
-                    return cbase[u] + (uint32_t)ca * csA + (uint32_t)cb * csB;
-                };
 #pragma unroll
-                for (int u = 0; u < 4; u++) vmax[u] = (int)lane < ncell[u] ? (uint32_t)skip_grid[cell_of(u, (int)lane)] : 0u;
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    for (int c = (int)lane + 64; c < ncell[u]; c += 64) vmax[u] = max(vmax[u], (uint32_t)skip_grid[cell_of(u, c)]);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < SU; u++) {
                     const bool visible = __any((int)vmax[u] > P.skip_thresh ? 1 : 0) != 0;
-                    if (visible && Lb + u <= Lhi && lane == 0) *reinterpret_cast<uint32_t *>(plan_b + (ptrdiff_t)(Lb + u) * plan_stride) |= 1u << 29;
+                    const int L = ((gb + u) << GL) + (int)lane;          // a lane per layer of the cell layer
+                    if (visible && (int)lane < G && L >= Llo && L <= Lhi) *reinterpret_cast<uint32_t *>(plan_b + (ptrdiff_t)L * plan_stride) |= 1u << 29;
                 }
             }
         }
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         }
     };
 
-    VR_TSLAB_STAT(unsigned st_samples = 0, st_iters = 0; const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();)
+    VR_TSLAB_STAT(unsigned st_samples = 0, st_iters = 0, st_skipped = 0, st_runs = 0; const uint64_t st_clk0 = clock64(), st_wall0 = wall_clock64();)
     VR_TSLAB_CHK(unsigned chk_violations = 0;)
     // The staged march, compiled once per major axis M (the tables of the minor axes are 16-bit, M's 32-bit; the layer of
     // a sample is its M index >> LSH).  PA = the voxel axis along which one LDS address yields a pair of taps (the apron
@@ -873,6 +882,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             }
             if (SKIP && !sampling) {
                 const int run = p_end - p;
+                VR_TSLAB_STAT(st_skipped += (unsigned)run; st_runs++;)
                 // the requests of the run's phases that a sampling phase behind the run reads (at most LA + 1 layers, consecutive)
                 const int ql = p + (int)lane;
                 uint64_t need = __ballot(((int)lane < run && layer_needed_lane(request_of(ql))) ? 1 : 0);
@@ -1129,7 +1139,8 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     if (spp && threadIdx.x == 2) { spp[pix] = (uint32_t)(wall_clock64() - st_wall0); return; }
     if (spp && threadIdx.x == 3) { spp[pix] = st_iters; return; }
     if (spp && threadIdx.x == 4) { spp[pix] = st_samples; return; }
-    if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; })   // set-up: ray, head, plan, tables
+    if (spp && threadIdx.x == 5) { spp[pix] = (uint32_t)(st_clk0 - st_entry); return; }     // set-up: ray, head, plan, tables
+    if (spp && threadIdx.x == 6) { spp[pix] = st_skipped | (st_runs << 16); return; })      // SKIP: phases crossed in empty runs, runs
     VR_TSLAB_CHK(if (spp) { spp[pix] = 0x40000000u | ((stage && any_prefix) ? 0x20000000u : 0u) | min(chk_violations, 0xffffu); return; })
     if (spp) spp[pix] = (uint32_t)i;
 }
