@@ -740,7 +740,7 @@ def config_extras(device):
                              window [1000, 5095] = the reference's +1000 quirk on [0, 4095], alpha 0.05: early ray termination
       cfg4_grey              2048^3 u8 (8 GiB, 64-bit offsets), 3840x2160, grey ramp, window [8, 255], alpha 0.004
       cfg4_tf_skip           the same through the default alpha-spline transfer function + exact empty-space skipping
-    cfg1 / cfg2 / cfg4_grey are also timed with TRILINEAR filtering (<name>_trilinear)."""
+    cfg1 / cfg2 / cfg4_grey are also timed with TRILINEAR filtering (<name>_trilinear), cfg4 with TRILINEAR + skipping in both modes."""
     import numpy as np
 
     vra = importlib.import_module("volume-renderer_amd")
@@ -813,6 +813,12 @@ def config_extras(device):
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
         r.setSkipEmpty(True)
         timed(r, "cfg4_tf_skip", 1, 3840, 2160, 10, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, tf_rgba=r.getTransferLut())
+        # north-star's config 4 in full: TRILINEAR + "adaptive step" (exact empty-space skipping, per tile and brick layer on the
+        # LDS-staged kernel) + the transfer function in LDS; and the grey ramp with skipping next to cfg4_grey_trilinear
+        r.setFilter(R.FILTER_TRILINEAR)
+        timed(r, "cfg4_tf_skip_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, tf_rgba=r.getTransferLut(), filter=1)
+        r.setTransferFunction()
+        timed(r, "cfg4_grey_skip_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, filter=1)
     return out
 
 
