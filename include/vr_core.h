@@ -152,7 +152,10 @@ int vr_set_filter(vr_handle h, int filter);          /* VR_FILTER_*  (F4)       
 int vr_set_accum(vr_handle h, int accum);            /* VR_ACCUM_*   (Q8)            */
 int vr_set_quirks(vr_handle h, uint32_t quirks);     /* VR_QUIRK_*                   */
 int vr_set_layout(vr_handle h, int layout);          /* VR_LAYOUT_* (default BRICKED); re-lays the volume out */
-int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping   */
+int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skipping (north-star's "adaptive step"): frames and sample
+                                                        counts are bit-identical with it; NEAREST kernels per ray and batch, the
+                                                        LDS-staged TRILINEAR kernel per tile and brick layer (round 5), tiles on
+                                                        global taps per ray and batch.  No reference equivalent                  */
 /* kernel selection: 0 = automatic (specialised kernels when the configuration allows; launches far from filling the
    chip -- fewer than 256 active 32x16 tiles, 1024 when the view is oblique to the volume axes -- use the 4-wavefront
    relay kernel; the fast kernel runs its software-pipelined batch loop unless alpha_scale >= 0.5),
