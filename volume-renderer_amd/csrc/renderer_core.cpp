@@ -1159,7 +1159,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // the threshold (window / transfer function), not only with the camera
     // (NEAREST skips per ray and batch: every pose.  The staged TRILINEAR kernel skips per tile and brick layer, and its tiles
     // that do not fit the ring skip nothing: where the view is oblique the estimate misjudges exactly the longest tiles -- the
-    // off-axis pose ran 1.46 / 1.55 / 2.2 ms depending on where they landed -- so there the order stays the geometric one)
+    // off-axis pose ran 1.46 / 1.55 / 2.2 ms depending on where they landed, and still 1.15 / 1.65 from one process to the next
+    // once those tiles skipped per batch -- so there the order stays the geometric one: 1.19-1.20 every time)
     const bool skip_order = P.skip_empty != 0 && L.skip_grid != nullptr && (filter == 0 || viewAxisAlignment(P) >= 0.92);
     const int64_t skip_sig = skip_order ? (int64_t)P.skip_thresh + 1 : 0;
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0) || skip_sig != tile_table_skip_sig_) {
