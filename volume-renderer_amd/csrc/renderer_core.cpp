@@ -50,6 +50,7 @@ RendererCore::~RendererCore()
         if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
         if (d_tile_work_) (void)hipFree(d_tile_work_);
+        if (d_skip_count_) (void)hipFree(d_skip_count_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
@@ -211,6 +212,7 @@ void RendererCore::freeVolume()
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
     res_dims_[0] = res_dims_[1] = res_dims_[2] = 0; res_bytes_ = 0;
     if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
+    skip_count_thresh_ = -0x7fffffff;
     if (tile_table_skip_sig_ != 0) tile_table_skip_sig_ = -1;            // (an order built on the old volume's visibility)
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
     vol12_failed_ = false;
@@ -1129,6 +1131,19 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
         check(e, "build skip grid");
         skip_grid_cells_ = cells;
     }
+    // nothing to skip at this threshold (a window that starts at the data's floor): the launch takes the instances without
+    // skipping -- theirs are the leaner loops (staged TRILINEAR 3.8 %, its tiles on global taps 20 %, the NEAREST kernels a
+    // workgroup of occupancy).  Counted once per threshold.
+    if (thresh != skip_count_thresh_) {
+        if (!d_skip_count_) check(hipMalloc(reinterpret_cast<void **>(&d_skip_count_), sizeof(unsigned long long)), "hipMalloc(skip count)");
+        check(launch_count_cells_le(d_skip_grid_, (uint64_t)cells, thresh, d_skip_count_, stream()), "count_cells_le_kernel");
+        unsigned long long n = 0;
+        check(hipMemcpyAsync(&n, d_skip_count_, sizeof(n), hipMemcpyDeviceToHost, stream()), "hipMemcpy(skip count)");
+        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
+        skip_empty_cells_ = n;
+        skip_count_thresh_ = thresh;
+    }
+    if (skip_empty_cells_ == 0) return;
     P.skip_empty = 1;
     P.skip_thresh = thresh;
     P.cnx = (int32_t)cnx; P.cny = (int32_t)cny; P.cnz = (int32_t)cnz;

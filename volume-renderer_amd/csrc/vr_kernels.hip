@@ -1921,6 +1921,25 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
     return hipGetLastError();
 }
 
+// how many cells of the dilated grid can be skipped at all for a threshold (host: refreshSkipGrid -- none: the launch runs the
+// instances without skipping, whose loops are a few percent leaner)
+__global__ __launch_bounds__(256) void count_cells_le_kernel(const uint16_t *__restrict__ grid, uint64_t cells, int thresh, unsigned long long *__restrict__ count)
+{
+    unsigned n = 0;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (uint64_t)gridDim.x * blockDim.x) n += (int)grid[c] <= thresh ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) n += (unsigned)__shfl_xor((int)n, o);
+    if ((threadIdx.x & 63u) == 0u && n != 0u) atomicAdd(count, (unsigned long long)n);
+}
+
+hipError_t launch_count_cells_le(const uint16_t *grid, uint64_t cells, int thresh, unsigned long long *count, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((cells + 255) / 256, 2048u);
+    hipLaunchKernelGGL(count_cells_le_kernel, dim3(blocks), dim3(256), 0, st, grid, cells, thresh, count);
+    return hipGetLastError();
+}
+
 // Expected cost of every tile under empty-space skipping (host: refreshTileSchedule).  The tile order is longest-first by the
 // tiles' expected ray lengths (tile_schedule.cpp); with skipping a ray's cost is the length of its VISIBLE stretch plus a small
 // share of the empty one, and a frame is only two or three rounds of tiles, so the order must know it: tiles through the
