@@ -788,6 +788,12 @@ def config_extras(device):
         out["cfg1_shape"]["data"] = Path(f).name if f else "synthetic sphere 256^3 u8"
         r.setFilter(R.FILTER_TRILINEAR)                      # the north-star's filter on the same configuration
         timed(r, "cfg1_shape_trilinear", 1, 1280, 720, 40, vol=vol, alpha_scale=1.0, min_val=0, max_val=255, filter=1)
+        # the same two with exact empty-space skipping switched on (the sphere sits in zeros: the space in front of it is skipped)
+        r.setSkipEmpty(True)
+        timed(r, "cfg1_shape_trilinear_skip", 1, 1280, 720, 40, vol=vol, alpha_scale=1.0, min_val=0, max_val=255, filter=1)
+        r.setFilter(R.FILTER_NEAREST)
+        timed(r, "cfg1_shape_skip", 1, 1280, 720, 40, vol=vol, alpha_scale=1.0, min_val=0, max_val=255)
+        r.setSkipEmpty(False)
     with renderer(1920, 1080) as r:
         f = os.environ.get("VR_DATA_HEAD")
         if f:
