@@ -194,3 +194,67 @@ def test_skipping_pays_and_is_invisible_at_full_size(vra, oracle):
             # touch the ball somewhere: measured -17 ... -25 % and -7 ... -9 %)
             # (the tiles on global taps, variant 7, skip per wavefront and batch: -11 % at the default pose)
             assert t_skip < (0.9 if pose == "default" and variant != 7 else 1.0) * t_plain, (pose, variant)
+
+
+def run_random_skip_trials(vra, oracle, seed, n_trials, log=None):
+    """randomised trials of skipping on every TRILINEAR path (and, every fourth trial, on the NEAREST kernels): random blob volumes
+    (dims, voxel type, spacing, background level), windows, opacities, modes, views, workgroup shapes, image sizes, cameras; each
+    frame with skipping must equal the frame without it AND the oracle's, per-pixel counts included.  tools/stress_skip.py runs
+    thousands.  Returns frames checked."""
+    rng = np.random.default_rng(seed)
+    R = vra.renderer
+    dims_pool = [(64, 64, 64), (96, 80, 72), (130, 33, 47), (40, 56, 24), (24, 24, 160), (8, 8, 8), (200, 40, 56), (72, 64, 80)]
+    n_checked = 0
+    for trial in range(n_trials):
+        dims = dims_pool[trial % len(dims_pool)]
+        dtype = np.uint8 if trial % 3 else np.uint16
+        hi = 255 if dtype == np.uint8 else 4095
+        bg = int(rng.integers(0, 9)) * (1 if dtype == np.uint8 else 12)
+        vol = blobs(rng, dims, dtype, bg)
+        spacing = (1.0, 1.0, 1.0) if trial % 3 == 0 else tuple(np.round(rng.uniform(0.4, 2.2, size=3), 3).tolist())
+        lo = int(rng.choice([0, bg, bg + 1, 2 * bg + 3])); hi_w = int(rng.integers(hi // 2, hi + 1))
+        alpha = float(np.float32(rng.choice([1.0, 0.3, 0.03, 0.0])))
+        W, H = int(rng.integers(24, 200)), int(rng.integers(24, 150))
+        mode = int(rng.integers(0, 6))
+        mip, tf = mode in (1, 3), mode in (2, 3)
+        top, bottom = (trial % 7 == 3), (trial % 7 == 5)
+        nearest = trial % 4 == 3
+        variant = 0 if nearest else int(rng.choice([0, 6, 7, 8, 9, 10]))
+        with vra.RendererCore(0) as r:
+            r.setup((W, H))
+            assert r.loadShader("VolumeRenderer.cs")
+            r.setQuirks(0)
+            r.setVolume(vol, spacing)
+            r.setFilter(R.FILTER_NEAREST if nearest else R.FILTER_TRILINEAR)
+            r.setWindow(lo, hi_w); r.setAlpha(alpha); r.setMIP(mip)
+            tf_lut = None
+            if tf:
+                z = int(rng.integers(1, 60))
+                r.setTransferFunction([0, z, z + 40, 160, 255], [[0, 0, 0, 0], [0, 0, 0, 0], [0.9, 0.2, 0.1, 0.3], [0.2, 0.8, 0.3, 0.1], [1, 1, 1, 0.9]])
+                tf_lut = r.getTransferLut()
+            if top or bottom:
+                r.setInitialCameraRotation(top, bottom)
+            r.setKernelVariant(variant)
+            for name, block in camera_blocks(oracle, rng, n_random=2)[int(rng.integers(0, 3))::3]:
+                r.setCameraBlock(block)
+                r.setSkipEmpty(False); r.render()
+                plain = r.readPixels()
+                r.setSkipEmpty(True); r.render()
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                what = (f"seed {seed} trial {trial} dims {dims} {np.dtype(dtype).name} spacing {spacing} bg {bg} window [{lo},{hi_w}] alpha {alpha} {W}x{H} mip {mip} tf {tf} "
+                        f"top {top} bottom {bottom} nearest {nearest} variant {variant} camera {name} kernel {r.last_kernel_name}")
+                assert np.array_equal(bits(plain), bits(got)), what
+                p = oracle.OracleParams(W, H, cam=block, alpha_scale=alpha, voxel_size=spacing, min_val=lo, max_val=hi_w, is_mip=int(mip), view_top=int(top),
+                                        view_bottom=int(bottom), tf_rgba=tf_lut, filter=0 if nearest else 1, threads=8)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                assert np.array_equal(spp, want_spp), what
+                assert np.array_equal(bits(got), bits(want)), what
+                n_checked += 1
+        if log and (trial + 1) % 200 == 0:
+            log(f"{trial + 1} trials, {n_checked} frames bit-exact")
+    return n_checked
+
+
+def test_randomised_skipping(vra, oracle):
+    assert run_random_skip_trials(vra, oracle, 20260930, 48) > 100
