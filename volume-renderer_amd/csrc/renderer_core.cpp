@@ -1177,7 +1177,9 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // off-axis pose ran 1.46 / 1.55 / 2.2 ms depending on where they landed, and still 1.15 / 1.65 from one process to the next
     // once those tiles skipped per batch -- so there the order stays the geometric one: 1.19-1.20 every time)
     const bool skip_order = P.skip_empty != 0 && L.skip_grid != nullptr && (filter == 0 || viewAxisAlignment(P) >= 0.92);
-    const int64_t skip_sig = skip_order ? (int64_t)P.skip_thresh + 1 : 0;
+    // (in 32nds of the data's range: a window slider dragged under skipping would otherwise rebuild the table -- host sort, device
+    // estimate, two synchronisations -- on every frame; the order is a heuristic and changes gradually with the threshold)
+    const int64_t skip_sig = skip_order ? 1 + ((int64_t)std::max(P.skip_thresh, 0) * 32) / std::max<int64_t>((int64_t)exact_max_ + 1, 1) : 0;
     if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0) || skip_sig != tile_table_skip_sig_) {
         std::vector<uint32_t> table;
         std::vector<float> work, work_tall;
