@@ -810,6 +810,12 @@ def config_extras(device):
         out["cfg2_shape_ert_window"]["data"] = Path(f).name if f else "synthetic noise ball 512x512x452 u16"
         r.setFilter(R.FILTER_TRILINEAR)
         timed(r, "cfg2_shape_ert_window_trilinear", 2, 1920, 1080, 40, vol=vol, alpha_scale=0.05, min_val=lo, max_val=hi, filter=1)
+        # ... and with exact empty-space skipping: everything at or below the window's lower end (the air around a CT scan) is skipped
+        r.setSkipEmpty(True)
+        timed(r, "cfg2_shape_ert_window_trilinear_skip", 2, 1920, 1080, 40, vol=vol, alpha_scale=0.05, min_val=lo, max_val=hi, filter=1)
+        r.setFilter(R.FILTER_NEAREST)
+        timed(r, "cfg2_shape_ert_window_skip", 2, 1920, 1080, 40, vol=vol, alpha_scale=0.05, min_val=lo, max_val=hi)
+        r.setSkipEmpty(False)
     with renderer(3840, 2160) as r:
         r.generateSynthetic(R.SYNTH_NOISE_BALL, (2048, 2048, 2048), 1, 0x9E3779B9)
         r.setWindow(8, 255); r.setAlpha(0.004)
@@ -828,6 +834,11 @@ def config_extras(device):
         timed(r, "cfg4_tf_skip_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, tf_rgba=r.getTransferLut(), filter=1)
         r.setTransferFunction()
         timed(r, "cfg4_grey_skip_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, filter=1)
+    for name, e in out.items():
+        if "skip" in name:
+            # S counts LOGICAL samples (the frame and the per-pixel counts are those of the launch without skipping); the skipped ones are
+            # never fetched, so this entry's roofline fraction is samples-per-second in bytes, not bytes moved -- `traffic` is what moved
+            e["empty_space_skipping"] = True
     return out
 
 

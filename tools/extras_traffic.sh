@@ -36,3 +36,5 @@ run cfg4_tf_skip_trilinear --volume 2048 --bytes 1 --width 3840 --height 2160 --
 run cfg4_grey_skip_trilinear --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --skip-empty --filter trilinear
 run cfg1_shape_trilinear_skip --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --filter trilinear --skip-empty
 run cfg1_shape_skip --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --skip-empty
+run cfg2_shape_ert_window_trilinear_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --filter trilinear --skip-empty
+run cfg2_shape_ert_window_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --skip-empty
