@@ -85,7 +85,38 @@ def cfg3():
                 check(r, f"cfg3 {name} variant {variant}")
 
 
+def skipping():
+    """exact empty-space skipping (round 5): layers nobody samples are not requested -- every staged tap must still find its layer asked for
+    (the checked build keeps a bit per requested layer) and inside the rectangle it was planned with"""
+    def blobs(dims, dtype, bg):
+        nx, ny, nz = dims
+        hi = 255 if dtype == np.uint8 else 4095
+        z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+        v = rng.integers(0, bg + 1, size=(nz, ny, nx)).astype(np.int64)
+        for _ in range(4):
+            c = [rng.uniform(0.15, 0.85) * n for n in (nx, ny, nz)]
+            rad = [rng.uniform(0.08, 0.3) * n + 1.5 for n in (nx, ny, nz)]
+            d2 = ((x - c[0]) / rad[0]) ** 2 + ((y - c[1]) / rad[1]) ** 2 + ((z - c[2]) / rad[2]) ** 2
+            v[d2 < 1.0] = np.maximum(v[d2 < 1.0], (hi * (1.0 - 0.7 * d2[d2 < 1.0])).astype(np.int64))
+        return np.clip(v, 0, hi).astype(dtype)
+    for dims, spacing, dtype in (((96, 80, 72), (1, 1, 1), np.uint16), ((130, 33, 47), (1.0, 0.8, 1.7), np.uint8), ((200, 168, 184), (1, 1, 1), np.uint16),
+                                 ((256, 256, 256), (1, 1, 1), np.uint8)):
+        bg = 6 if dtype == np.uint8 else 60
+        vol = blobs(dims, dtype, bg)
+        with vra.RendererCore(0) as r:
+            r.setup((200, 144) if dims[0] < 200 else (320, 208)); r.loadShader("x"); r.setQuirks(0)
+            r.setVolume(vol, spacing); r.setFilter(R.FILTER_TRILINEAR); r.setSkipEmpty(True)
+            for lo, alpha in ((bg, 0.03), (3 * bg, 1.0)):
+                r.setWindow(lo, 4095 if dtype == np.uint16 else 255); r.setAlpha(alpha)
+                for name, block in cams(3):
+                    r.setCameraBlock(block)
+                    for variant in (6, 8, 9, 10):
+                        r.setKernelVariant(variant); r.render()
+                        check(r, f"skipping {dims} {np.dtype(dtype).name} window lo {lo} {name} variant {variant}")
+
+
 small_volumes()
+skipping()
 if "full" in sys.argv:
     cfg3()
 print(json.dumps(report))

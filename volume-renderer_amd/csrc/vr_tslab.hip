@@ -136,7 +136,10 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     __shared__ float corner[5][4];              // rows 0..3: G of the corner rays, row 4: E (voxel coordinates)
     __shared__ int red[12];                     // 0: min first progress, 1: max last progress, 2: max prefix length, 3 / 4: max rectangle extents,
                                                 // 5: clamp flag, 6..9: min / max brick index of the live rectangles along a and b
-    static_assert(sizeof(corner) + sizeof(red) <= C::MISC_BYTES, "LDS budget");
+    // checked build: one bit per planned layer that was REQUESTED (issue_layer) -- with empty-space skipping a layer is fetched only
+    // when some sampling phase reads it, and check_taps() holds every staged tap to "its layer was asked for"
+    VR_TSLAB_CHK(constexpr int CHK_REQ_WORDS = 64; __shared__ uint32_t chk_req[CHK_REQ_WORDS];)
+    static_assert(sizeof(corner) + sizeof(red) VR_TSLAB_CHK(+ 64 * 4) <= C::MISC_BYTES, "LDS budget");
 
     const uint32_t t = tile_table[blockIdx.x];
     if (t == 0xffffffffu) return;                                       // padding block
@@ -679,6 +682,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             }
         }
     }
+    VR_TSLAB_CHK(if (threadIdx.x < (unsigned)CHK_REQ_WORDS) chk_req[threadIdx.x] = 0u;)
     __syncthreads();
     const uint32_t ring_base = lds_offset_of(slots);
     // SKIP: does layer X hold anything visible (per lane; everything does without skipping) / is it read by a phase that samples --
@@ -716,6 +720,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // A phase's instructions outside the sample loop are not what its time follows)
     auto issue_layer = [&](int L) {
         if (L < Llo || L > Lhi) return;
+        VR_TSLAB_CHK(if (threadIdx.x == 0 && L - Llo < 32 * CHK_REQ_WORDS) atomicOr(&chk_req[(L - Llo) >> 5], 1u << ((L - Llo) & 31));)
         const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)L * plan_stride);
         const uint32_t ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
         const int lo_a = (int)(ex & 0xffffu), lo_b = (int)((ex >> 16) & LOB_MASK);
@@ -817,6 +822,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
                     // resident in phase L: L and the layer above it (the + 1 taps), one more in the marching direction when the ring is four deep
                     const int lo_res = sgn > 0 ? L : L - (LA >= 2 ? 1 : 0), hi_res = sgn > 0 ? L + 1 + (LA >= 2 ? 1 : 0) : L + 1;
                     if (lyr < lo_res || lyr > hi_res || lyr < Llo || lyr > Lhi) { bad++; continue; }
+                    if (lyr - Llo < 32 * CHK_REQ_WORDS && ((chk_req[(lyr - Llo) >> 5] >> ((lyr - Llo) & 31)) & 1u) == 0u) { bad++; continue; }   // never requested
                     const uint2 e = *reinterpret_cast<const uint2 *>(plan_b + (ptrdiff_t)lyr * plan_stride);
                     const int lo_a = (int)(e.x & 0xffffu), lo_b = (int)((e.x >> 16) & LOB_MASK), dda = (int)(e.y & 255u), ddb = (int)((e.y >> 8) & 255u);
                     const int ba = ia >> 2, bb = jb >> 2;
