@@ -175,6 +175,9 @@ int vr_set_skip_empty(vr_handle h, int enable);      /* exact empty-space skippi
    diagonal).  16-bit volumes; on 8-bit ones 8 runs as 6 and 9 as 6 on 16x32-pixel tiles.
    10 = the shape of 6 on 53 KiB of LDS: three workgroups per CU, six wavefronts per SIMD -- faster (6-13 %) wherever the tiles' brick
    layers fit (8-bit volumes, 16-bit ones up to ~512^3 or at 4K), slower where they do not; a candidate of the measured choice.
+   11 = the LDS-staged kernel on 16x16-pixel tiles (four wavefronts, 40 KiB, four workgroups per CU; 16-bit volumes at oblique views
+   with the per-axis copies and the thickness per tile): the first guess for volumes up to 640 voxels per axis, a candidate for
+   launches that leave workgroup slots empty (round 6: cfg1 shape 0.138 -> 0.118 ms, cfg2 shape 0.402 -> 0.381).
    Frames are bit-identical under every variant. */
 int vr_set_kernel_variant(vr_handle h, int variant);
 /* 1 (default): under kernel variant 0 the launch is a MEASURED choice -- every candidate kernel of a configuration
@@ -187,7 +190,7 @@ int vr_set_kernel_variant(vr_handle h, int variant);
 int vr_set_autotune(vr_handle h, int enable);
 /* what the last launch ran as (for tests and tools; no reference equivalent): bit 0 relay kernel, bit 1 pipelined batch loop,
    bit 2 four-sample batches, bits 3..6 the LDS-staged trilinear kernel's shape (0 = not that kernel; the numbers of
-   vr_set_kernel_variant 6 .. 10 minus 5), bit 8 (256): the measured choice is still EXPLORING this configuration -- the
+   vr_set_kernel_variant 6 .. 11 minus 5), bit 8 (256): the measured choice is still EXPLORING this configuration -- the
    frame was a trial of one candidate (up to ~45 % slower than the settled choice), not the settled kernel */
 int vr_get_launch_choice(vr_handle h);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the

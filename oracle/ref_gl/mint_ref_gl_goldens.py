@@ -58,6 +58,10 @@ SPH64 = ("sphere", 64, 28)
 SPH256 = ("sphere", 256, 112)
 CFG2 = ("noise", (512, 512, 452), 2, 0x9E3779B9)
 CFG3U8 = ("noise", (1024, 1024, 1024), 1, 0x9E3779B9)
+# round 6: the largest 16-bit volume llvmpipe accepts at cfg3's x/y extent -- 1024 x 1024 x 448 uint16 = 0.94 GiB (the cap is
+# 1 GiB per texture) -- and, for the filtered path, 1024 x 1024 x 224 as R32F (0.94 GiB)
+CFG3SLAB = ("noise", (1024, 1024, 448), 2, 0x9E3779B9)
+CFG3SLABTRI = ("noise", (1024, 1024, 224), 2, 0x9E3779B9)
 SMALL16 = ("noise", (48, 40, 36), 2, 7)
 ODD8 = ("noise", (37, 53, 29), 1, 3)
 ORBIT_A = [(0.0, 0.06 * 7, 0.06 * 9)]
@@ -95,6 +99,11 @@ CASES = {
     "cfg3_geom_u8_deep": dict(vol=CFG3U8, img=(1920, 1080), alpha=0.004, window=(0, 255), rows=60),
     "cfg3_geom_u8_shallow": dict(vol=CFG3U8, img=(1920, 1080), alpha=1.0, window=(0, 255), rows=60),
     "cfg3_geom_u8_offaxis": dict(vol=CFG3U8, img=(1920, 1080), alpha=0.004, window=(0, 255), rows=60, cam=OFFAXIS),
+    # cfg3's x/y extent with 16-bit voxels (u16 bricks + the 12-bit packed copy + the address tables of the HIP path at 1024 x 1024),
+    # the window [0, 4095] uploaded as [1000, 5095] (Q10); three regimes like cfg3_geom_u8_*
+    "cfg3_slab_u16_deep": dict(vol=CFG3SLAB, img=(1920, 1080), alpha=0.004, window=(0, 4095), rows=60),
+    "cfg3_slab_u16_shallow": dict(vol=CFG3SLAB, img=(1920, 1080), alpha=1.0, window=(0, 4095), rows=60),
+    "cfg3_slab_u16_offaxis": dict(vol=CFG3SLAB, img=(1920, 1080), alpha=0.004, window=(0, 4095), rows=60, cam=OFFAXIS),
 }
 
 
@@ -138,6 +147,8 @@ CASES.update({
     "tri_cfg1_shape_a0.02": dict(vol=SPH256, img=(1280, 720), alpha=0.02, window=(0, 255), rows=40, **TRI),
     "tri_cfg2_shape_window": dict(vol=CFG2, img=(1920, 1080), alpha=0.05, window=(0, 4095), rows=60, **TRI),
     "tri_cfg2_shape_offaxis": dict(vol=CFG2, img=(1920, 1080), alpha=0.01, window=(0, 4095), rows=60, cam=OFFAXIS, **TRI),
+    "tri_cfg3_slab_u16_deep": dict(vol=CFG3SLABTRI, img=(1920, 1080), alpha=0.004, window=(0, 4095), rows=60, **TRI),
+    "tri_cfg3_slab_u16_offaxis": dict(vol=CFG3SLABTRI, img=(1920, 1080), alpha=0.004, window=(0, 4095), rows=60, cam=OFFAXIS, **TRI),
 })
 for _k, _c in _random_cases(8, seed=20260930).items():
     CASES["tri_" + _k] = dict(_c, **TRI)
@@ -215,13 +226,23 @@ def measure_f4():
 
 def main():
     OUT_DIR.mkdir(parents=True, exist_ok=True)
-    manifest = {"gl": ref_gl.gl_info(), "shader_sha256": hashlib.sha256(ref_gl.SHADER_PATH.read_bytes()).hexdigest(),
-                "deviation": "volume texture MIN/MAG filter GL_NEAREST instead of GL_LINEAR (see f4)",
-                "clear_value": CLEAR, "cases": {}}
-    manifest["f4"] = measure_f4()
-    print("F4:", json.dumps(manifest["f4"]))
+    # --only SUBSTRING: mint the matching cases and merge them into the committed manifest (the other entries and frames are
+    # left as they are; same GL, same shader -- asserted)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    head = {"gl": ref_gl.gl_info(), "shader_sha256": hashlib.sha256(ref_gl.SHADER_PATH.read_bytes()).hexdigest(),
+            "deviation": "volume texture MIN/MAG filter GL_NEAREST instead of GL_LINEAR (see f4)", "clear_value": CLEAR}
+    if only is not None:
+        manifest = json.loads(MANIFEST.read_text())
+        for k, v in head.items():
+            assert manifest[k] == v, (k, manifest[k], v)
+    else:
+        manifest = dict(head, cases={})
+        manifest["f4"] = measure_f4()
+        print("F4:", json.dumps(manifest["f4"]))
     vols = {}
     for name, c in CASES.items():
+        if only is not None and only not in name:
+            continue
         key = repr(c["vol"])
         if key not in vols:
             vols.clear()   # one big volume at a time
@@ -257,6 +278,8 @@ def main():
         }
         print(f"{name:26s} {dt:6.2f}s  rows {len(rows):4d}  alpha px {manifest['cases'][name]['pixels_with_alpha']:8d}  {manifest['cases'][name]['frame_sha256'][:16]}",
               flush=True)
+    if only is not None:      # keep the manifest in CASES order
+        manifest["cases"] = {n: manifest["cases"][n] for n in CASES if n in manifest["cases"]}
     MANIFEST.write_text(json.dumps(manifest, indent=1) + "\n")
     print("wrote", MANIFEST)
 

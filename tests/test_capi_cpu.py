@@ -163,7 +163,7 @@ def test_argument_validation(vra):
     with pytest.raises(vra.VRError):
         r.setup((0, 10))
     for bad in (lambda: r.setFilter(7), lambda: r.setAccum(-1), lambda: r.setLayout(5), lambda: r.setRowRange(5, 2),
-                lambda: r.setRowStripes(0, 0, 2), lambda: r.setRowStripes(8, 3, 2), lambda: r.setKernelVariant(11), lambda: r.setKernelVariant(4)):
+                lambda: r.setRowStripes(0, 0, 2), lambda: r.setRowStripes(8, 3, 2), lambda: r.setKernelVariant(12), lambda: r.setKernelVariant(4)):
         with pytest.raises(vra.VRError) as e:
             bad()
         assert e.value.code == vra.renderer.VR_E_INVALID

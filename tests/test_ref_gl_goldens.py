@@ -247,7 +247,7 @@ def test_three_rounding_lerps_are_within_tolerance_but_not_the_gl_filter(oracle,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 2, 6, 7], ids=["generic", "batched", "staged", "unstaged"])
+@pytest.mark.parametrize("variant", [1, 2, 6, 7, 11], ids=["generic", "batched", "staged", "unstaged", "small"])
 @pytest.mark.parametrize("name", ["tri_cfg0_a0.05", "tri_cfg0_mip_top", "tri_cfg0_bottom_inside", "tri_u16_small_window", "tri_u8_odd_dims", "tri_rnd_02"])
 def test_hip_trilinear_kernel_families_reproduce_the_gl_linear_filter(vra, oracle, name, variant):
     c = CASES[name]

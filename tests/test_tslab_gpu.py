@@ -60,7 +60,7 @@ def cameras(oracle, rng, n_random=3):
                          ids=["cube64", "noncubic", "odd_dims", "aniso", "tiny", "one_voxel", "thin", "cube256"])
 # 7: every tile on the path of tiles that do not fit LDS; 8 / 9 / 10 (16-bit volumes; the 8-bit runs take variant 6's kernel): per-major-axis
 # copies and half layers where whole ones do not fit, on 32x16 tiles / 32x32 tiles on a CU's whole LDS / 32x16 tiles on the whole LDS / 16x32 tiles (11)
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10], ids=["staged", "unstaged", "half", "halftall", "three"])
+@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11], ids=["staged", "unstaged", "half", "halftall", "three", "small"])
 def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing, variant):
     rng = np.random.default_rng((sum(d * 31 ** k for k, d in enumerate(dims)) * 7 + np.dtype(dtype).itemsize) % (2 ** 32))
     vol = rand_volume(rng, dims, dtype, smooth=dims[0] >= 96)
@@ -95,7 +95,7 @@ def test_tri_slab_kernel_matches_oracle(vra, oracle, dtype, dims, spacing, varia
 
 @pytest.mark.parametrize("mode", ["mip", "tf", "mip_tf", "top", "bottom", "mip_top", "tf_bottom"])
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10], ids=["staged", "unstaged", "half", "halftall", "three"])
+@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11], ids=["staged", "unstaged", "half", "halftall", "three", "small"])
 def test_tri_slab_kernel_modes_and_views(vra, oracle, dtype, mode, variant):
     rng = np.random.default_rng(5)
     dims, spacing = (72, 64, 80), (1.0, 1.0, 1.0)
@@ -205,7 +205,7 @@ def test_tri_slab_full_size_cfg3(vra, oracle):
             if pose == "offaxis":
                 r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
             frames, counts, kernels, ms = {}, {}, {}, {}
-            for name, variant in (("staged", 6), ("half", 8), ("halftall", 9), ("three", 10), ("batched", 2), ("generic", 1)):
+            for name, variant in (("staged", 6), ("half", 8), ("halftall", 9), ("three", 10), ("small", 11), ("batched", 2), ("generic", 1)):
                 r.setKernelVariant(variant)
                 r.render(); r.kernelMsTake()
                 for _ in range(3):
@@ -215,7 +215,7 @@ def test_tri_slab_full_size_cfg3(vra, oracle):
                 frames[name] = r.readPixels().copy()
                 counts[name] = r.countSamples()
             print(f"cfg3 trilinear {pose}: " + ", ".join(f"{k} {kernels[k]} {ms[k]:.3f} ms" for k in ms))
-            assert kernels == {"staged": TSLAB, "half": TSLAB, "halftall": TSLAB, "three": TSLAB, "batched": "raymarch_tri_kernel", "generic": "raymarch_generic_kernel"}
+            assert kernels == {"staged": TSLAB, "half": TSLAB, "halftall": TSLAB, "three": TSLAB, "small": TSLAB, "batched": "raymarch_tri_kernel", "generic": "raymarch_generic_kernel"}
             assert counts["staged"] == counts["half"] == counts["halftall"] == counts["three"] == counts["batched"] == counts["generic"]
             for k in ("staged", "half", "halftall", "three"):
                 assert np.array_equal(bits(frames[k]), bits(frames["generic"])), (pose, k)

@@ -56,7 +56,7 @@ def camera_blocks(oracle, rng, n_random=2):
 @pytest.mark.parametrize("dims,spacing", [((96, 80, 72), (1, 1, 1)), ((130, 33, 47), (1.0, 0.8, 1.7)), ((200, 168, 184), (1, 1, 1)), ((7, 5, 3), (1, 1, 1))],
                          ids=["noncubic", "odd_aniso", "mid", "tiny"])
 # (7: every tile on the path of tiles that do not fit LDS -- it skips per ray and batch of four samples)
-@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10], ids=["staged", "unstaged", "half", "halftall", "three"])
+@pytest.mark.parametrize("variant", [6, 7, 8, 9, 10, 11], ids=["staged", "unstaged", "half", "halftall", "three", "small"])
 def test_skipping_is_invisible_grey(vra, oracle, dtype, dims, spacing, variant):
     rng = np.random.default_rng(sum(d * 17 ** k for k, d in enumerate(dims)) + np.dtype(dtype).itemsize + variant)
     hi = 255 if dtype == np.uint8 else 4095
@@ -98,7 +98,7 @@ def test_skipping_is_invisible_grey(vra, oracle, dtype, dims, spacing, variant):
 
 @pytest.mark.parametrize("mode", ["mip", "tf", "mip_tf", "top", "bottom", "tf_top", "tf_hole"])
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
-@pytest.mark.parametrize("variant", [6, 7, 8, 10], ids=["staged", "unstaged", "half", "three"])
+@pytest.mark.parametrize("variant", [6, 7, 8, 10, 11], ids=["staged", "unstaged", "half", "three", "small"])
 def test_skipping_is_invisible_modes_and_views(vra, oracle, dtype, mode, variant):
     rng = np.random.default_rng(11)
     dims = (88, 72, 96)
@@ -196,6 +196,46 @@ def test_skipping_pays_and_is_invisible_at_full_size(vra, oracle):
             assert t_skip < (0.9 if pose == "default" and variant != 7 else 1.0) * t_plain, (pose, variant)
 
 
+def test_skipping_on_a_long_axis_unstaged_oblique(vra, oracle):
+    """round-5 advisor: the tiles on global taps (variant 7) probe the skip grid at positions from a closed form; on an axis of
+    thousands of voxels its error must not grow with the ray's length (the probes are re-anchored every 16 batches).  A 4096-voxel
+    axis crossed obliquely, blobs with empty space between them, every batch decision checked through the frame and the counts."""
+    R = vra.renderer
+    rng = np.random.default_rng(4096)
+    # (spacings that fatten the short axes: the box is about 1 x 0.4 x 0.45, so rays ALONG the long axis take thousands of steps)
+    for dims, dtype, spacing in (((4096, 40, 48), np.uint8, (1.0, 40.0, 38.0)), ((48, 2304, 40), np.uint16, (20.0, 1.0, 26.0))):
+        hi = 255 if dtype == np.uint8 else 4095
+        vol = blobs(rng, dims, dtype, 3)
+        # the long axis repeated: blobs() spans the whole volume, so cut gaps of background every few hundred voxels
+        ax = 2 - int(np.argmax(dims))
+        idx = np.arange(vol.shape[ax])
+        gap = ((idx // 160) % 2 == 1)
+        sl = [slice(None)] * 3; sl[ax] = gap
+        vol[tuple(sl)] = np.minimum(vol[tuple(sl)], 2)
+        with vra.RendererCore(0) as r:
+            r.setup((160, 96))
+            assert r.loadShader("VolumeRenderer.cs")
+            r.setQuirks(0)
+            r.setVolume(vol, spacing)
+            r.setFilter(R.FILTER_TRILINEAR); r.setWindow(3, hi); r.setAlpha(0.01)
+            for name, (dz, da) in {"along_x": (0.15, (np.pi / 2) / 0.7 + 0.2), "along_y": ((np.pi / 2) / 0.7 - 0.25, 0.3), "oblique": (0.5, 0.9)}.items():
+                c = oracle.Camera(); c.orient(0, dz, da)
+                block = c.block()
+                r.setCameraBlock(block)
+                p = oracle.OracleParams(160, 96, cam=block, alpha_scale=0.01, voxel_size=spacing, min_val=3, max_val=hi, filter=1, threads=8)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                assert int(want_spp.max()) > 800, (name, int(want_spp.max()))       # rays do run along the long axis (thousands of steps at the matching pose)
+                for variant in (7, 6, 0):
+                    r.setKernelVariant(variant)
+                    r.setSkipEmpty(True); r.render()
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    what = f"{dims} {np.dtype(dtype).name} camera {name} variant {variant} kernel {r.last_kernel_name}"
+                    assert r.last_kernel_name == TSLAB, what
+                    assert np.array_equal(spp, want_spp), what
+                    assert np.array_equal(bits(got), bits(want)), what
+
+
 def run_random_skip_trials(vra, oracle, seed, n_trials, log=None):
     """randomised trials of skipping on every TRILINEAR path (and, every fourth trial, on the NEAREST kernels): random blob volumes
     (dims, voxel type, spacing, background level), windows, opacities, modes, views, workgroup shapes, image sizes, cameras; each
@@ -219,7 +259,7 @@ def run_random_skip_trials(vra, oracle, seed, n_trials, log=None):
         mip, tf = mode in (1, 3), mode in (2, 3)
         top, bottom = (trial % 7 == 3), (trial % 7 == 5)
         nearest = trial % 4 == 3
-        variant = 0 if nearest else int(rng.choice([0, 6, 7, 8, 9, 10]))
+        variant = 0 if nearest else int(rng.choice([0, 6, 7, 8, 9, 10, 11]))
         with vra.RendererCore(0) as r:
             r.setup((W, H))
             assert r.loadShader("VolumeRenderer.cs")

@@ -62,14 +62,14 @@ def small_volumes():
             r.setVolume(vol, spacing); r.setFilter(R.FILTER_TRILINEAR); r.setWindow(0, 4095 if dtype == np.uint16 else 255); r.setAlpha(0.02)
             for name, block in cams(4):
                 r.setCameraBlock(block)
-                for variant in (6, 8, 9, 10):
+                for variant in (6, 8, 9, 10, 11):
                     r.setKernelVariant(variant); r.render()
                     check(r, f"{dims} {spacing} {np.dtype(dtype).name} {name} variant {variant}")
             for top, bottom in ((True, False), (False, True)):
                 r.setInitialCameraRotation(top, bottom)
                 for name, block in cams(1)[:4]:
                     r.setCameraBlock(block)
-                    for variant in (6, 8):
+                    for variant in (6, 8, 11):
                         r.setKernelVariant(variant); r.render()
                         check(r, f"{dims} view {'top' if top else 'bottom'} {name} variant {variant}")
 
@@ -80,7 +80,7 @@ def cfg3():
         r.generateSynthetic(R.SYNTH_NOISE_BALL, (1024,) * 3, 2, 0x9E3779B9); r.setWindow(0, 4095); r.setAlpha(0.004); r.setFilter(R.FILTER_TRILINEAR)
         for name, block in cams(3):
             r.setCameraBlock(block)
-            for variant in (6, 8, 9, 10):
+            for variant in (6, 8, 9, 10, 11):
                 r.setKernelVariant(variant); r.render()
                 check(r, f"cfg3 {name} variant {variant}")
 
@@ -110,7 +110,7 @@ def skipping():
                 r.setWindow(lo, 4095 if dtype == np.uint16 else 255); r.setAlpha(alpha)
                 for name, block in cams(3):
                     r.setCameraBlock(block)
-                    for variant in (6, 8, 9, 10):
+                    for variant in (6, 8, 9, 10, 11):
                         r.setKernelVariant(variant); r.render()
                         check(r, f"skipping {dims} {np.dtype(dtype).name} window lo {lo} {name} variant {variant}")
 

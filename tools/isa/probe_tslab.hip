@@ -11,5 +11,5 @@ namespace vr {
 #define PROBE_PERM false
 #endif
 template __global__ void raymarch_tslab_kernel<uint16_t, 0, 0, true, 0, PROBE_NW, PROBE_LDSKB, PROBE_PERM>(const FrameParams, const uint16_t *, const uint8_t *, const uint8_t *, const uint8_t *, const float4 *, float4 *, uint32_t *,
-                                                                                               const uint32_t *, const int);
+                                                                                               const uint32_t *, const int, const uint16_t *);
 }

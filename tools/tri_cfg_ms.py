@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """TRILINEAR kernel ms of the cfg1 / cfg2 shapes (bench.py: config_extras) under kernel variants 2 (batched), 6 (LDS-staged),
 7 (staged kernel, staging off), 0 (measured choice), sustained clocks"""
-import importlib, sys
+import importlib, os, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 vra = importlib.import_module("volume-renderer_amd")
@@ -24,7 +24,7 @@ for name, size, synth, dims, b, seed, win, alpha in (("cfg1", (1280, 720), R.SYN
     r.generateSynthetic(synth, dims, b, seed)
     r.setWindow(*win); r.setAlpha(alpha); r.setFilter(R.FILTER_TRILINEAR)
     out = {}
-    for v in (2, 6, 7, 0):
+    for v in [int(x) for x in os.environ.get("VR_VARIANTS", "2,6,7,10,11,0").split(",")]:
         r.setKernelVariant(v)
         out[v] = (round(ms(r), 4), r.last_kernel_name.replace("raymarch_", ""))
     r.setFilter(R.FILTER_NEAREST); r.setKernelVariant(0)

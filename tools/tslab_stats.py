@@ -11,10 +11,17 @@ R = vra.renderer
 pose = sys.argv[1] if len(sys.argv) > 1 else "default"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 b = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+import os
 W, H = (1920, 1080) if N <= 1024 else (3840, 2160)
+PRESET = os.environ.get("VR_STATS_PRESET", "")          # "cfg1": bench.py's cfg1 shape (256^3 u8 sphere, 1280x720, alpha 1)
+if PRESET == "cfg1":
+    W, H, N, b = 1280, 720, 256, 1
 r = vra.RendererCore(0)
 r.setup((W, H)); r.loadShader("x"); r.setQuirks(0)
-r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
+if PRESET == "cfg1":
+    r.generateSynthetic(R.SYNTH_SPHERE_U8, (N, N, N), 1, 112)
+else:
+    r.generateSynthetic(R.SYNTH_NOISE_BALL, (N, N, N), b, 0x9E3779B9)
 r.setWindow(0, 4095 if b == 2 else 255); r.setAlpha(float(sys.argv[4]) if len(sys.argv) > 4 else 0.004); r.setFilter(R.FILTER_TRILINEAR)
 if pose == "offaxis":
     r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
@@ -23,7 +30,7 @@ elif "," in pose:                       # "zenith,azimuth" as passed to cameraOr
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 6
 if len(sys.argv) > 6 and int(sys.argv[6]) > 0:
     r.setWindow(int(sys.argv[6]), 4095 if b == 2 else 255); r.setSkipEmpty(True)
-TH, TWP = (32, 16) if variant == 9 else (16, 32)              # rows per tile
+TH, TWP = (32, 16) if variant == 9 else ((16, 16) if variant == 11 else (16, 32))              # rows / columns per tile
 r.setKernelVariant(variant)
 r.render()
 print("kernel", r.last_kernel_name)

@@ -49,6 +49,7 @@ RendererCore::~RendererCore()
         if (d_tf_) (void)hipFree(d_tf_);
         if (d_tile_table_) (void)hipFree(d_tile_table_);
         if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
+        if (d_tile_table_small_) (void)hipFree(d_tile_table_small_);
         if (d_tile_work_) (void)hipFree(d_tile_work_);
         if (d_skip_count_) (void)hipFree(d_skip_count_);
         if (d_spp_) (void)hipFree(d_spp_);
@@ -633,8 +634,8 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
     L.mip = u_.is_MIP;
     L.layout = vol_layout_;
     L.generic = force_generic == 1 ? 1 : 0;
-    // kernel variants 6 .. 10: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
-    L.tri_slab = (force_generic >= 6 && force_generic <= 10) ? force_generic - 5 : 0;
+    // kernel variants 6 .. 11: TRILINEAR on the LDS-staged kernel wherever it is eligible, in one of its shapes (0: see refreshTileSchedule)
+    L.tri_slab = (force_generic >= 6 && force_generic <= 11) ? force_generic - 5 : 0;
     L.pipelined = 0;
     L.short_batches = 0;
     // 32-bit voxel offsets with 24-bit multiplies (VoxelAddr) whenever the volume allows
@@ -696,7 +697,7 @@ float4 *RendererCore::prepareLaunch(FrameParams &P, LaunchConfig &L)
     refreshPacked12(P, L);
     refreshApron(P, L);
     // (the half-layer shapes need the per-axis copies: without them -- allocation failed -- the round-3 choice)
-    if (L.tri_slab >= 3 && (L.apron_y == nullptr || L.apron_x == nullptr) && force_generic == 0) L.tri_slab = tri_path_candidate(P, L) ? 0 : 1;
+    if ((L.tri_slab == 3 || L.tri_slab == 4) && (L.apron_y == nullptr || L.apron_x == nullptr) && force_generic == 0) L.tri_slab = tri_path_candidate(P, L) ? 0 : 1;
     // the specialised kernels gather from the packed copy when their address tables fit (vr_kernels.hip: dispatch_fast3)
     last_packed12_bytes_ = (L.packed12 && P.nx + P.ny + P.nz <= 3072) ? (size_t)L.packed12_bytes : 0;
     tuneChoose(P, L);
@@ -738,6 +739,15 @@ void RendererCore::launch(uint32_t *spp)
 // central ray keeps this share of its length along one volume axis: at 0.973 (a fifth of a voxel of shear per voxel) the
 // per-tile layer thickness already wins, 1.33 against 1.46 ms on cfg3; at 1.0 whole layers do, 1.17 against 1.20
 static constexpr double kTriWholeLayerAlignment = 0.985;
+// TRILINEAR: the small tile shape (16x16 pixels, four wavefronts, 40 KiB) is offered to the measured choice -- and is the first guess --
+// where a tile's brick layers are small against its ring: volumes up to 640 voxels along every axis (cfg1 shape 0.138 -> 0.118 ms, cfg2
+// shape 0.402 -> 0.381), and larger ones only while the launch leaves workgroup slots empty (fewer than two 32x16-pixel tiles per
+// slot of the chip, 256 CUs x 2).  A 1024^3 volume filling the screen loses (1.12 -> 1.22 ms; oblique 1.55 -> 2.74).
+static bool tri_small_tiles_offered(const FrameParams &P, const LaunchConfig &L, unsigned tile_active)
+{
+    if (L.tile_table_small == nullptr) return false;
+    return std::max(P.nx, std::max(P.ny, P.nz)) <= 640 || tile_active < 1024u;
+}
 
 // ---- the measured work model.  Which kernel is fastest for a launch depends on how many tiles have work, how long
 // their rays are, how early they end and how oblique the view is (tools/config_sweep.py: the relay kernel wins a
@@ -816,6 +826,8 @@ void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
         add(prior);
         add(1 << 3);
         add(5 << 3);                                                     // three workgroups per CU: wins where the tiles' layers fit 53 KiB
+        // 16x16-pixel tiles on four wavefronts: launches whose 32x16-pixel tiles leave workgroup slots empty (two per CU)
+        if (tri_small_tiles_offered(P, L, tile_active_)) add(6 << 3);
         if (tri_path_candidate(P, L)) add(0);
         if (L.apron_y != nullptr && L.apron_x != nullptr) {
             add(3 << 3);
@@ -997,7 +1009,8 @@ void RendererCore::refreshApron(const FrameParams &P, LaunchConfig &L)
     // and either a half-layer shape is forced (variants 8 / 9) or the automatic choice may pick one -- the heuristic's first
     // guess for an oblique view, or a candidate of the measured choice.  Both or none: a lone copy is freed again.
     const bool oblique = viewAxisAlignment(P) < kTriWholeLayerAlignment;
-    const bool half_layers_possible = (force_generic >= 8 && force_generic <= 9) || (force_generic == 0 && oblique && (L.tri_slab >= 3 || autotune));
+    const bool half_layers_possible = (force_generic >= 8 && force_generic <= 9) || (force_generic == 11 && oblique) ||
+                                      (force_generic == 0 && oblique && (L.tri_slab >= 3 || autotune));
     const bool want_perm = res_bytes_ == 2 && tri_slab_candidate(P, L) && L.tile_table != nullptr && half_layers_possible;
     if (want_perm && !apron_perm_failed_ && !(d_apron_perm_[0] && d_apron_perm_[1])) {
         if (!copyFits(2 * (bytes + 16))) apron_perm_failed_ = true;     // (re-armed by vr_set_copy_budget and by the next volume)
@@ -1064,7 +1077,7 @@ void RendererCore::residentBytes(uint64_t &volume, uint64_t &copies, uint64_t &o
     const uint64_t px = (uint64_t)framebuffer_size[0] * (uint64_t)framebuffer_size[1];
     other = (d_fb_ ? px * 16 : 0) + (d_tf_ ? 256 * 16 : 0) + (uint64_t)spp_capacity_ * 4 + (d_scratch_ ? 264 * 4 : 0) +
             (d_skip_grid_ ? (uint64_t)skip_grid_cells_ * 2 : 0) + (uint64_t)rgba8_capacity_ + (uint64_t)present_capacity_ * kPresentSlots +
-            ((uint64_t)tile_table_capacity_ + (uint64_t)tile_table_tall_capacity_ + (uint64_t)tile_work_capacity_) * 4;
+            ((uint64_t)tile_table_capacity_ + (uint64_t)tile_table_tall_capacity_ + (uint64_t)tile_table_small_capacity_ + (uint64_t)tile_work_capacity_) * 4;
 }
 
 // Exact empty-space skipping (vr_set_skip_empty): the fast kernel may skip a batch of
@@ -1159,6 +1172,8 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     L.tile_table_blocks = 0;
     L.tile_table_tall = nullptr;
     L.tile_table_tall_blocks = 0;
+    L.tile_table_small = nullptr;
+    L.tile_table_small_blocks = 0;
     if (!tile_order || !(fast_path_eligible(P, L) || tri_path_candidate(P, L) || tri_slab_candidate(P, L))) return;
     const int rows = launch_local_rows(P);
     if (rows <= 0) return;
@@ -1170,6 +1185,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     float drift = 0.0f;
     for (int i = 0; i < 21; i++) drift = std::max(drift, std::fabs(P.cam[i] - tile_table_cam_[i]));
     const bool need32 = filter == 1 && tri_slab_candidate(P, L) && (P.stripe_count <= 1 || P.stripe_rows % 32 == 0 || force_generic == 9);   // 16x32-pixel tiles for the staged trilinear kernel's tall shape
+    const bool need16 = filter == 1 && tri_slab_candidate(P, L);       // 16x16-pixel tiles for its small shape (four wavefronts; any stripe height that is a multiple of 16)
     // empty-space skipping: the order follows the tiles' VISIBLE work (vr_kernels.hip: tile_visible_work_kernel); it changes with
     // the threshold (window / transfer function), not only with the camera
     // (NEAREST skips per ray and batch: every pose.  The staged TRILINEAR kernel skips per tile and brick layer, and its tiles
@@ -1180,9 +1196,10 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // (in 32nds of the data's range: a window slider dragged under skipping would otherwise rebuild the table -- host sort, device
     // estimate, two synchronisations -- on every frame; the order is a heuristic and changes gradually with the threshold)
     const int64_t skip_sig = skip_order ? 1 + ((int64_t)std::max(P.skip_thresh, 0) * 32) / std::max<int64_t>((int64_t)exact_max_ + 1, 1) : 0;
-    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0) || skip_sig != tile_table_skip_sig_) {
+    if (shape_key != tile_table_key_ || !d_tile_table_ || !(drift <= 0.05f) || (need32 && tile_table_tall_blocks_ == 0) || (need16 && tile_table_small_blocks_ == 0) ||
+        skip_sig != tile_table_skip_sig_) {
         std::vector<uint32_t> table;
-        std::vector<float> work, work_tall;
+        std::vector<float> work, work_tall, work_small;
         if (skip_order) {
             // (one small kernel and a synchronous copy per table, only when the table is rebuilt; an empty sample costs about
             // a seventh of a sampled one in both kernel families)
@@ -1202,6 +1219,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
             };
             estimate(kFastTileW, kFastTileH, work);
             if (need32) estimate(16u, 32u, work_tall);
+            if (need16) estimate(16u, 16u, work_small);
         }
         tile_active_ = buildTileSchedule(P, rows, table, &tile_longest_, kFastTileH, kFastTileW, skip_order ? work.data() : nullptr);
         // synchronous copies: the tables are pageable temporaries
@@ -1222,6 +1240,12 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
             (void)buildTileSchedule(P, rows, tall, nullptr, 32u, 16u, skip_order ? work_tall.data() : nullptr);
             upload(d_tile_table_tall_, tile_table_tall_capacity_, tile_table_tall_blocks_, tall);
         }
+        tile_table_small_blocks_ = 0;
+        if (need16) {
+            std::vector<uint32_t> small;
+            tile_active_small_ = buildTileSchedule(P, rows, small, nullptr, 16u, 16u, skip_order ? work_small.data() : nullptr);
+            upload(d_tile_table_small_, tile_table_small_capacity_, tile_table_small_blocks_, small);
+        }
         tile_table_key_ = shape_key;
         tile_table_skip_sig_ = skip_sig;
         std::memcpy(tile_table_cam_, P.cam, sizeof(tile_table_cam_));
@@ -1229,6 +1253,7 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     L.tile_table = d_tile_table_;
     L.tile_table_blocks = (uint32_t)tile_table_blocks_;
     if (need32 && tile_table_tall_blocks_ > 0) { L.tile_table_tall = d_tile_table_tall_; L.tile_table_tall_blocks = (uint32_t)tile_table_tall_blocks_; }
+    if (need16 && tile_table_small_blocks_ > 0) { L.tile_table_small = d_tile_table_small_; L.tile_table_small_blocks = (uint32_t)tile_table_small_blocks_; }
     // Kernel choice per launch (all bit-identical; measured on cfg3 after the checked-head fix, tools/pose_sweep.py and
     // tools/shard_ms.py; `aligned` = central ray within ~23 degrees of a volume axis):
     //   * relay kernel (4 wavefronts per 8x8 tile) for launches far from filling the chip -- fewer than 256 active
@@ -1245,7 +1270,9 @@ void RendererCore::refreshTileSchedule(const FrameParams &P, LaunchConfig &L)
     // layers (round 4: orbit poses 1.43-1.62 ms against 2.9-3.4 whole-layer / 2.6-3.0 batched), on 16x32-pixel tiles with the
     // ring's rows holding their own brick ranges when the view runs near a body diagonal of the volume (1.68 ms against 3.0).
     if (force_generic == 0 && filter == 1 && tri_slab_candidate(P, L)) {
-        if (viewAxisAlignment(P) >= kTriWholeLayerAlignment || L.bytes_per_voxel == 1) {
+        if (std::max(P.nx, std::max(P.ny, P.nz)) <= 640 && L.tile_table_small != nullptr) {
+            L.tri_slab = 6;                                              // small volumes: 16x16-pixel tiles (round 6)
+        } else if (viewAxisAlignment(P) >= kTriWholeLayerAlignment || L.bytes_per_voxel == 1) {
             L.tri_slab = 1;
         } else {
             double r1, r2;

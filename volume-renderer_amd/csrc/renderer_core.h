@@ -192,6 +192,9 @@ private:
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;
     uint32_t *d_tile_table_tall_ = nullptr;  // the same for 16x32-pixel tiles (the staged trilinear kernel's tall shape); built with the table above
     size_t tile_table_tall_capacity_ = 0, tile_table_tall_blocks_ = 0;
+    uint32_t *d_tile_table_small_ = nullptr; // the same for 16x16-pixel tiles (the staged trilinear kernel's four-wavefront shape)
+    size_t tile_table_small_capacity_ = 0, tile_table_small_blocks_ = 0;
+    unsigned tile_active_small_ = 0;
     uint64_t tile_table_key_ = 0;
     int64_t tile_table_skip_sig_ = 0;        // what the order was built for: 0 = geometric ray lengths, threshold + 1 = visible work under empty-space skipping (-1: rebuild)
     float *d_tile_work_ = nullptr;           // per-tile cost estimates of that (scratch of refreshTileSchedule)

@@ -331,7 +331,7 @@ int vr_set_autotune(vr_handle h, int enable)
 int vr_set_kernel_variant(vr_handle h, int variant)
 {
     return guarded(h, [&](vr::RendererCore &c) {
-        if (variant < 0 || variant > 10 || variant == 4) throw std::invalid_argument("unknown kernel variant");   // 4: retired in round 3
+        if (variant < 0 || variant > 11 || variant == 4) throw std::invalid_argument("unknown kernel variant");   // 4: retired in round 3
         c.force_generic = variant;
     });
 }

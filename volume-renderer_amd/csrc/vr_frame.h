@@ -85,12 +85,14 @@ struct LaunchConfig {
     uint32_t tile_table_blocks;
     const uint32_t *tile_table_tall;   // device: the same for 16x32-pixel tiles (8 wavefronts, 2 x 4: the staged trilinear kernel's tall shape; nullptr = none)
     uint32_t tile_table_tall_blocks;
+    const uint32_t *tile_table_small;  // device: the same for 16x16-pixel tiles (4 wavefronts, 2 x 2: the staged trilinear kernel's small shape; nullptr = none)
+    uint32_t tile_table_small_blocks;
     const void *packed12;          // device: 12-bit packed copy of the bricked u16 volume (nullptr = none)
     uint32_t packed12_bytes;
     const void *apron;             // device: TRILINEAR's apron copy of the volume (nullptr = none; vr_device.h)
     const void *apron_y, *apron_x; // device: the apron copy with the bricks' planes along y / x slowest (orders 1 and 2 of relayout_apron_kernel; nullptr = none): half layers of the staged kernel
     uint64_t apron_bytes;          // (beyond 4 GiB only the LDS-staged trilinear kernel uses it: no buffer descriptor)
-    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16-pixel tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 3 = 16-bit volumes: per-axis copies and the layer thickness per tile (variant 8); 4 = 16x32-pixel tiles with rows (variant 9; 16-bit volumes as 3, 8-bit ones with whole layers); 5 = as 1 on 53 KiB, three workgroups per CU (variant 10)
+    int tri_slab;                  // TRILINEAR on the LDS-staged kernel where eligible (vr_tslab.hip): 1 = 32x16-pixel tiles, order-0 copy, whole layers (kernel variant 6); 2 = that with staging switched off (variant 7); 3 = 16-bit volumes: per-axis copies and the layer thickness per tile (variant 8); 4 = 16x32-pixel tiles with rows (variant 9; 16-bit volumes as 3, 8-bit ones with whole layers); 5 = as 1 on 53 KiB, three workgroups per CU (variant 10); 6 = 16x16-pixel tiles on four wavefronts and 40 KiB, four workgroups per CU (variant 11; 16-bit volumes with the per-axis copies when they are resident)
     int short_batches;             // fast kernel with 4-sample batches (rays expected to end early: alpha_scale >= 0.5)
     int pipelined;                 // fast kernel with the software-pipelined batch loop (under-filled launches; vr_set_kernel_variant 5 forces it)
 };

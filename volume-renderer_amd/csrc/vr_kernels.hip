@@ -979,25 +979,38 @@ __global__ __launch_bounds__(512) void raymarch_tri_kernel(const FrameParams P, 
 // alpha, sample count per ray; one sequence word published with release/acquire at
 // workgroup scope).  Every sample still goes through exactly the shader's operations in
 // the shader's order; only WHICH wavefront executes them changes.
+// Round 6: the ray POSITIONS no longer travel.  Rounds 1-5 handed the position at the start of
+// batch n + 1 from the wavefront that had generated batch n's addresses to the next one through
+// LDS -- a second serial chain of ~130 hand-overs beside the compositing one.  The positions do
+// not depend on the data, so every wavefront now iterates the shader's additions itself, in the
+// shader's order (32 per axis between its own batches n and n + 4: the four wavefronts perform
+// each addition four times instead of once, in issue slots a sparse launch leaves idle).  One
+// rank's shard of the cfg3 frame at N = 8: 0.106 -> 0.084 ms, N = 4: 0.182 -> 0.153 (now ahead of
+// the fast kernel's 0.163), bit-identical frames (profiles/r06_relay_own_positions.txt).
 // Same preconditions as the fast kernel's headline shape (NEAREST, grey-ramp composite,
 // iterative accumulation, default view, 32-bit offsets, alpha_scale in [0,1]).
 // measured on cfg3: 2 or 8 wavefronts per tile, batches of 16, 4 tiles per workgroup are all slower
-constexpr int RELAY_WAVES = 4, RELAY_BATCH = 8;
+// (round 6, with the wavefronts' own positions: six or eight wavefronts per tile, one tile per workgroup: N = 8 shard 0.150 / 0.148 ms
+// against 0.087 -- profiles/r06_relay_own_positions.txt)
+#ifndef VR_RELAY_WAVES
+#define VR_RELAY_WAVES 4
+#define VR_RELAY_BATCH 8
+#define VR_RELAY_TILES 2
+#endif
+constexpr int RELAY_WAVES = VR_RELAY_WAVES, RELAY_BATCH = VR_RELAY_BATCH;
 // two tiles share one workgroup (and one 32 KiB classification table): 4 workgroups = 8 tiles
 // = 32 wavefronts per CU, the wave-slot limit, instead of 4 tiles per CU
-constexpr int RELAY_TILES = 2, RELAY_THREADS = 64 * RELAY_WAVES * RELAY_TILES;
+constexpr int RELAY_TILES = VR_RELAY_TILES, RELAY_THREADS = 64 * RELAY_WAVES * RELAY_TILES;
 
 struct RelayState {
     float rgb[2][64];      // red (== green == blue in the grey modes)
     float g[2][64], b[2][64];   // green / blue: only the transfer-function modes carry them
     float a[2][64];
     int i[2][64];
-    float pos[2][3][64];   // ray position at the start of batch n (slot n & 1)
-    unsigned seq;          // number of batches composited so far
-    unsigned pseq;         // number of batches whose positions have been generated
-    unsigned stop;         // set when no ray of the tile needs another batch
+    unsigned seq;          // number of batches composited so far; bit 31: no ray of the tile needs another batch (one word: one LDS load per poll)
     unsigned final_n;      // the state slot holding the result is final_n & 1
 };
+constexpr unsigned RELAY_STOP = 0x80000000u;
 
 // VIEW / MODE as in the fast kernel (round 2: every mode and view of a sparse shard gets the relay)
 template <typename VoxelT, int LAYOUT, int DIVTC, bool LUT, bool POW2, bool NOCLAMP, bool ATAB, bool PK12, int VIEW, int MODE>
@@ -1018,11 +1031,12 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     // block b -> (32x16 tile of the longest-first table, pair of 8x8 sub-tiles); the 4 pairs of
     // a tile are consecutive blocks of ONE XCD (b & 7 is the XCD)
     const unsigned b = blockIdx.x;
-    const uint32_t tile = tile_table[(b >> 5) * 8u + (b & 7u)];
+    constexpr unsigned GROUPS = 8u / RELAY_TILES;                        // workgroups per 32x16-pixel tile
+    const uint32_t tile = tile_table[(b / (8u * GROUPS)) * 8u + (b & 7u)];
     if (tile == 0xffffffffu) return;
     const unsigned tl = threadIdx.x / (64u * RELAY_WAVES);              // tile of this wavefront within the workgroup
     RelayState &rs = rs_all[tl];
-    const unsigned sub = ((b >> 3) & 3u) * RELAY_TILES + tl;
+    const unsigned sub = ((b >> 3) % GROUPS) * RELAY_TILES + tl;
     const unsigned lane = threadIdx.x & 63u, w = (threadIdx.x >> 6) % RELAY_WAVES;
     const int lx = (int)((tile & 0xffffu) * FAST_TILE_W + (sub & 3u) * 8u + (lane & 7u));
     const int ly = (int)((tile >> 16) * FAST_TILE_H + (sub >> 2) * 8u + (lane >> 3));
@@ -1076,7 +1090,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     }
     if (ATAB && any_hit) build_axis_tables<VoxelT, LAYOUT, PK12>(P, axis_tab, RELAY_THREADS);
     if (w == 0) { rs.rgb[0][lane] = 0.0f; rs.g[0][lane] = 0.0f; rs.b[0][lane] = 0.0f; rs.a[0][lane] = 0.0f; rs.i[0][lane] = 0; }
-    if (w == 0 && lane == 0) { rs.seq = 0u; rs.pseq = 0u; rs.stop = 0u; rs.final_n = 0u; }
+    if (w == 0 && lane == 0) { rs.seq = 0u; rs.final_n = 0u; }
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)vol, 0, (int)vol_bytes, 0x00020000);
@@ -1129,32 +1143,34 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     const int wmin = P.min_val - pkb, wmax = P.max_val - pkb;
     const int lut_bias = MODE >= 2 ? FAST_TF_ENTRIES * 16 - wmin : -8 * wmin;
 
-    // The ray positions travel the same way as the compositing state: the wavefront that
-    // generated the addresses of batch n publishes the position at the start of batch n+1
-    // (every addition is the shader's, performed once, in order).
-    if (w == 0) {
-        rs.pos[0][0][lane] = POW2 ? qx * Sx : qx; rs.pos[0][1][lane] = POW2 ? qy * Sy : qy; rs.pos[0][2][lane] = POW2 ? qz * Sz : qz;
-    }
-    __syncthreads();
-    // both wait loops give up when the tile has been stopped (early ray termination of every
-    // ray, or the last batch): returns false, nothing may be touched any more
-    auto wait_for = [&](const unsigned *word, int n) -> bool {
-        while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)n) {
-            if (__hip_atomic_load(&rs.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
-            __builtin_amdgcn_s_sleep(1);
+    // waits until `n` batches have been composited; gives up when the tile has been stopped (early ray termination
+    // of every ray, or the last batch): returns false, nothing may be touched any more
+    auto wait_seq = [&](int n) -> bool {
+        for (;;) {
+            const unsigned v = __hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (v & RELAY_STOP) return false;
+            if ((v & ~RELAY_STOP) >= (unsigned)n) return true;
+            // (no s_sleep between the polls: a relay launch leaves the SIMDs' issue slots idle anyway, and the 64-cycle naps sat on
+            // the compositing chain -- N = 8 shard 0.087 -> 0.082 ms, N = 4 0.155 -> 0.152, N = 2 0.286 -> 0.278)
         }
-        return __hip_atomic_load(&rs.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
     };
     bool stopped = false;
-    auto take_position = [&](int n, float &x, float &y, float &z) -> bool {
-        if (!wait_for(&rs.pseq, n)) return false;
-        x = rs.pos[n & 1][0][lane]; y = rs.pos[n & 1][1][lane]; z = rs.pos[n & 1][2][lane];
-        return true;
+    // this wavefront's own copy of the ray position, at the start of batch own_n: the shader's additions (one fma with the
+    // multiplicand 1.0 IS the addition; 0.0 keeps the position of a ray whose prefix has ended), every one of them, in order
+    float ox = POW2 ? qx * Sx : qx, oy = POW2 ? qy * Sy : qy, oz = POW2 ? qz * Sz : qz;
+    int own_n = 0;
+    auto own_advance_to = [&](int n) {
+        for (; own_n < n; own_n++) {
+            const float vf = own_n < nb ? 1.0f : 0.0f;
+#pragma unroll
+            for (int u = 0; u < RELAY_BATCH; u++) { ox = __builtin_fmaf(mx, vf, ox); oy = __builtin_fmaf(my, vf, oy); oz = __builtin_fmaf(mz, vf, oz); }
+        }
     };
     // gathers of batch n (if this ray still needs them); returns whether v[] is valid
     auto issue = [&](int n, uint32_t (&v)[RELAY_BATCH], uint32_t &nib, float da_seen) -> bool {
-        float x = 0.0f, y = 0.0f, z = 0.0f;
-        if (stopped || !take_position(n, x, y, z)) { stopped = true; return false; }
+        if (stopped || (__hip_atomic_load(&rs.seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & RELAY_STOP)) { stopped = true; return false; }
+        own_advance_to(n);
+        float x = ox, y = oy, z = oz;
         const bool need = n < nb && da_seen < 0.95f;
         uint32_t off[RELAY_BATCH];
         if (n < nb) {
@@ -1183,9 +1199,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
                 x += mx; y += my; z += mz;
             }
         }
-        // position at the start of batch n + 1
-        rs.pos[(n + 1) & 1][0][lane] = x; rs.pos[(n + 1) & 1][1][lane] = y; rs.pos[(n + 1) & 1][2][lane] = z;
-        if (lane == 0) __hip_atomic_store(&rs.pseq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ox = x; oy = y; oz = z; own_n = n + 1;           // the position at the start of batch n + 1
         if (need) {
 #pragma unroll
             for (int u = 0; u < RELAY_BATCH; u++) {
@@ -1242,7 +1256,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
                 classify(PK12 ? __builtin_amdgcn_ubfe(v[u], __builtin_amdgcn_ubfe(nib, 4 * u, 4), 12) : v[u], c[u], cg[u], cb[u], a[u]);
             }
         }
-        if (stopped || !wait_for(&rs.seq, n)) { stopped = true; return; }
+        if (stopped || !wait_seq(n)) { stopped = true; return; }
         const int slot = n & 1;
         float drgb = rs.rgb[slot][lane], da = rs.a[slot][lane], dg = 0.0f, db = 0.0f;
         if (MODE >= 2) { dg = rs.g[slot][lane]; db = rs.b[slot][lane]; }
@@ -1273,14 +1287,12 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         // does any ray of the tile need another batch?  (terminated rays and rays whose prefix
         // ends here do not)
         const bool more = hit && da < 0.95f && n + 1 < nb;
-        if (!__any(more ? 1 : 0)) {
-            if (lane == 0) {
-                rs.final_n = (unsigned)(n + 1);
-                __hip_atomic_store(&rs.stop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        const bool last = !__any(more ? 1 : 0);
+        if (last) {
+            if (lane == 0) rs.final_n = (unsigned)(n + 1);
             stopped = true;
         }
-        if (lane == 0) __hip_atomic_store(&rs.seq, (unsigned)(n + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&rs.seq, (unsigned)(n + 1) | (last ? RELAY_STOP : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     {
@@ -1332,12 +1344,9 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     float drgb = rs.rgb[fin & 1][lane], da = rs.a[fin & 1][lane], dg = 0.0f, db = 0.0f;
     if (MODE >= 2) { dg = rs.g[fin & 1][lane]; db = rs.b[fin & 1][lane]; }
     int i = rs.i[fin & 1][lane];
-    {
-        // a ray that still needs its tail finished its prefix at batch nb <= fin <= pseq, and its
-        // position has not changed since; pos(pseq) is the latest published
-        const unsigned pn = rs.pseq;
-        qx = rs.pos[pn & 1][0][lane]; qy = rs.pos[pn & 1][1][lane]; qz = rs.pos[pn & 1][2][lane];
-    }
+    // a ray that still needs its tail finished its prefix at batch nb <= fin, and its position has not changed since
+    own_advance_to((int)fin);
+    qx = ox; qy = oy; qz = oz;
     if (POW2) { qx = qx / Sx; qy = qy / Sy; qz = qz / Sz; }   // exact: S is a power of two
     const float tsx = POW2 ? mx / Sx : mx, tsy = POW2 ? my / Sy : my, tsz = POW2 ? mz / Sz : mz;
     if (hit && !head_ended) {

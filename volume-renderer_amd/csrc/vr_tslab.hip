@@ -74,7 +74,8 @@ template <typename VoxelT, int MODE, int NW, int LDSKB, bool PERM, int TW = 4>
 struct TslabCfg {
     static constexpr int THREADS = 64 * NW;                                       // TW x NW/TW wavefronts of 8x8 pixels
     static constexpr int TILE_W = 8 * TW, TILE_H = 8 * (NW / TW);
-    static constexpr int WAVES_PER_SIMD = (LDSKB <= 53 ? 3 : (LDSKB <= 80 ? 2 : 1)) * NW / 4;   // workgroups per CU: 3 / 2 / 1
+    static constexpr int WGS_PER_CU = LDSKB <= 26 ? 6 : (LDSKB <= 32 ? 5 : (LDSKB <= 40 ? 4 : (LDSKB <= 53 ? 3 : (LDSKB <= 80 ? 2 : 1))));   // what 160 KiB hold
+    static constexpr int WAVES_PER_SIMD = WGS_PER_CU * NW / 4;
     static constexpr int BRICK_BYTES = (int)APRON_BRICK_VOXELS * (int)sizeof(VoxelT);   // a brick of the apron copies: 80 B (u8) / 160 B (u16)
     static constexpr int LUT_BYTES = MODE >= 2 ? 4096 : 16;                       // 256 premultiplied RGBA entries
     static constexpr int MISC_BYTES = 512;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
     // rows (the ring's rows with their own brick ranges, below): compiled into the 16x32-pixel shapes only -- the views that need rows are
     // the ones those tiles suit, and the other shapes keep their leaner phase loop (with the rows' loader and table producer compiled in,
     // tiles that never use them run 2-4 % slower: measured on every shape)
-    constexpr bool ROWS = TW == 2;
+    constexpr bool ROWS = TW == 2 && NW == 8;
     constexpr int TS_NW = NW, TS_THREADS = C::THREADS;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::REGION];
     __shared__ __attribute__((aligned(16))) float lut[C::LUT_BYTES / 4];
@@ -1080,18 +1081,23 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             // inside the loop ran 3x SLOWER than sampling, 1.38 -> 4.2 ms with every tile on this path: vector-memory operations
             // complete in order and the compiler cannot count them across the loop's two paths, so every iteration waited for the
             // probe it had just issued, and a skipped batch has nothing to hide that behind)
-            float V0x = 0.0f, V0y = 0.0f, V0z = 0.0f, dVx = 0.0f, dVy = 0.0f, dVz = 0.0f;   // voxel coordinates of the position k steps from here: V0 + k dV
+            // (round-5 advisor: the probes are RE-ANCHORED at the marched position every FB_AHEAD batches -- V0 is evaluated from the
+            // current position, k counts from there -- so the closed form's error is bounded by 64 steps' worth, k * N * 2^-23 voxels =
+            // a quarter voxel on a 32768-voxel axis, instead of growing over the whole prefix; and a step may advance at most THREE voxels
+            // per axis: 1.5 steps + the tap's 1.5 voxels stay 2 voxels inside the 8 the dilated grid covers beyond the probe's cell)
+            float V0x = 0.0f, V0y = 0.0f, V0z = 0.0f, dVx = 0.0f, dVy = 0.0f, dVz = 0.0f;   // voxel coordinates of the position k steps from the anchor: V0 + k dV
             bool fb_skip = false;
+            const float rSx = 1.0f / Sx, rSy = 1.0f / Sy, rSz = 1.0f / Sz;   // (POW2: exact)
+            auto fb_anchor = [&]() { voxel_float(POW2 ? Qx * rSx : qx, POW2 ? Qy * rSy : qy, POW2 ? Qz * rSz : qz, V0x, V0y, V0z); };
             if (skip_on) {
-                const float rSx = 1.0f / Sx, rSy = 1.0f / Sy, rSz = 1.0f / Sz;   // (POW2: exact)
                 const float bx = POW2 ? Qx * rSx : qx, by = POW2 ? Qy * rSy : qy, bz = POW2 ? Qz * rSz : qz;
                 float ex, ey, ez;
-                voxel_float(bx, by, bz, V0x, V0y, V0z);
+                fb_anchor();
                 voxel_float(bx + dsx, by + dsy, bz + dsz, ex, ey, ez);
                 dVx = ex - V0x; dVy = ey - V0y; dVz = ez - V0z;
-                fb_skip = fmaxf(fmaxf(fabsf(dVx), fabsf(dVy)), fabsf(dVz)) <= 4.0f;
+                fb_skip = fmaxf(fmaxf(fabsf(dVx), fabsf(dVy)), fabsf(dVz)) <= 3.0f;
             }
-            auto fb_probe = [&](float k) -> uint32_t {                   // grid value at the position k steps from where this loop started
+            auto fb_probe = [&](float k) -> uint32_t {                   // grid value at the position k steps from the anchor
                 const float fx = __builtin_fmaf(k, dVx, V0x), fy = __builtin_fmaf(k, dVy, V0y), fz = __builtin_fmaf(k, dVz, V0z);
                 const int ci = min((int)fmaxf(fx - 0.5f, 0.0f) >> 3, P.cnx - 1), cj = min((int)fmaxf(fy - 0.5f, 0.0f) >> 3, P.cny - 1);
                 const int ck = min((int)fmaxf(fz - 0.5f, 0.0f) >> 3, P.cnz - 1);
@@ -1101,10 +1107,11 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
             constexpr int FB_AHEAD = 16;                                 // batches probed together
             uint32_t emask = 0u;                                         // bit j: batch j from here is empty
             int eleft = 0;                                               // batches the mask still covers
-            float kf = 0.0f;                                             // samples taken since the loop started
+            float kf = 0.0f;                                             // samples taken since the probes' anchor
             while (rem >= TS_FB_BATCH && !done) {
                 if (fb_skip) {
                     if (eleft == 0) {
+                        fb_anchor(); kf = 0.0f;                          // the anchor moves to where the ray stands now
                         emask = 0u;
 #pragma unroll
                         for (int j = 0; j < FB_AHEAD; j++)
@@ -1206,14 +1213,14 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
 }
 
 // ------------------------------------------------------------------ dispatch
-// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4 / 6: u8; 1 .. 3, 5: u16 (below)
+// One translation unit per (voxel type, workgroup shape): VR_TSLAB_TU = 0 / 4 / 6 / 7: u8; 1 .. 3, 5, 8, 9: u16 (below)
 template <typename VoxelT, int NW, int LDSKB, bool PERM, int TW, int DIVTC, int VIEW, bool POW2, int MODE, bool SKIP>
 static hipError_t launch_tslab2(const FrameParams &P, const LaunchConfig &L, const void *vol, const float4 *tf, float4 *fb,
                                 uint32_t *spp, hipStream_t st)
 {
-    static_assert(NW == 8, "tile tables exist for 8-wavefront tiles");
-    const uint32_t *table = TW == 2 ? L.tile_table_tall : L.tile_table;
-    const uint32_t blocks = TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks;
+    static_assert((NW == 8 && (TW == 4 || TW == 2)) || (NW == 4 && TW == 2), "tile tables exist for 32x16-, 16x32- and 16x16-pixel tiles");
+    const uint32_t *table = NW == 4 ? L.tile_table_small : (TW == 2 ? L.tile_table_tall : L.tile_table);
+    const uint32_t blocks = NW == 4 ? L.tile_table_small_blocks : (TW == 2 ? L.tile_table_tall_blocks : L.tile_table_blocks);
     int no_stage = L.tri_slab == 2 ? 1 : 0;
     VR_TSLAB_CHK(if (std::getenv("VR_TSLAB_SABOTAGE") != nullptr) no_stage = 3;)   // checked build only: the plan guard's negative control
     hipLaunchKernelGGL((raymarch_tslab_kernel<VoxelT, DIVTC, VIEW, POW2, MODE, NW, LDSKB, PERM, TW, SKIP>), dim3(blocks), dim3(64 * NW), 0, st, P,
@@ -1269,6 +1276,8 @@ static hipError_t dispatch_tslab(const FrameParams &P, const LaunchConfig &L, co
 //   tri_slab 4: 16x32-pixel tiles (two wavefronts wide, four tall), rows for the tiles that fit no other way; 16-bit volumes with
 //               the per-axis copies and the thickness per tile, 8-bit ones with whole layers
 //   tri_slab 5: the shape of 1 on 53 KiB, three workgroups per CU (8- and 16-bit volumes)
+//   tri_slab 6: 16x16-pixel tiles, four wavefronts, 40 KiB: four workgroups per CU (round 6; 16-bit volumes with the per-axis copies and the
+//               thickness per tile when those copies are resident, whole layers from the order-0 copy otherwise)
 // (round 4 also measured, and did not keep: whole layers only on a CU's whole LDS -- 32x16 tiles 1.96-2.13 ms over the orbit poses,
 // 32x32 tiles with 16 wavefronts 1.64-3.6 --; half layers on 32x32 tiles / 160 KiB 1.63-1.89, off-axis 2.73; half layers on 32x16 tiles
 // with the whole LDS 1.90-2.06, off-axis 2.39: behind the two shapes above at every pose once the 16x32 tiles had rows)
@@ -1277,6 +1286,9 @@ hipError_t launch_tslab_u16_halftall(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u8_tall(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u16_three(VR_TSLAB_ARGS);
 hipError_t launch_tslab_u8_three(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u8_small(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_small(VR_TSLAB_ARGS);
+hipError_t launch_tslab_u16_smallperm(VR_TSLAB_ARGS);
 
 #ifndef VR_TSLAB_TU
 #define VR_TSLAB_TU -1
@@ -1286,6 +1298,7 @@ hipError_t launch_raymarch_slab_tri_u8(VR_TSLAB_ARGS)
 {
     if (L.tri_slab == 4 && L.tile_table_tall != nullptr) return launch_tslab_u8_tall(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 5) return launch_tslab_u8_three(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 6 && L.tile_table_small != nullptr) return launch_tslab_u8_small(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint8_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -1296,6 +1309,8 @@ hipError_t launch_raymarch_slab_tri_u16(VR_TSLAB_ARGS)
     if (L.tri_slab == 3 && perm_ok) return launch_tslab_u16_half(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 4 && perm_ok && L.tile_table_tall != nullptr) return launch_tslab_u16_halftall(P, L, vol, tf, fb, spp, st);
     if (L.tri_slab == 5) return launch_tslab_u16_three(P, L, vol, tf, fb, spp, st);
+    if (L.tri_slab == 6 && L.tile_table_small != nullptr)
+        return perm_ok ? launch_tslab_u16_smallperm(P, L, vol, tf, fb, spp, st) : launch_tslab_u16_small(P, L, vol, tf, fb, spp, st);
     return dispatch_tslab<uint16_t, 8, 80, false>(P, L, vol, tf, fb, spp, st);
 }
 #endif
@@ -1314,9 +1329,24 @@ hipError_t launch_tslab_u16_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_
 #if VR_TSLAB_TU == 6 || VR_TSLAB_TU == -1
 hipError_t launch_tslab_u8_three(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 8, 53, false>(P, L, vol, tf, fb, spp, st); }
 #endif
+// round 6: 16x16-pixel tiles on FOUR wavefronts and 40 KiB, four workgroups per CU (tri_slab 6): what pays where a tile's brick layers are
+// small against the ring -- volumes up to ~512^3, launches that leave workgroup slots empty -- because twice as many tiles end the launch
+// with a shorter longest tile and barriers join four wavefronts instead of eight (cfg1 shape 0.138 -> 0.118 ms, cfg2 shape 0.402 -> 0.381);
+// a 1024^3 volume's layers do not fit 40 KiB three deep (default pose 1.12 -> 1.22 ms, off-axis 1.55 -> 2.74: 40 % of the tiles on global
+// taps), so the work model offers the shape only below that size.  (Measured and dropped: the same tiles on 26 KiB, six workgroups per
+// CU at 80 VGPRs -- cfg1 0.1175 vs 0.1186 ms, cfg2 0.3808 vs 0.3810: nothing for another translation unit.)
+#if VR_TSLAB_TU == 7 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u8_small(VR_TSLAB_ARGS) { return dispatch_tslab<uint8_t, 4, 40, false, 2>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 8 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_small(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 4, 40, false, 2>(P, L, vol, tf, fb, spp, st); }
+#endif
+#if VR_TSLAB_TU == 9 || VR_TSLAB_TU == -1
+hipError_t launch_tslab_u16_smallperm(VR_TSLAB_ARGS) { return dispatch_tslab<uint16_t, 4, 40, true, 2>(P, L, vol, tf, fb, spp, st); }
+#endif
 
 // one empty kernel per translation unit (like vr_kernels.hip's warm_kernel_*): launching it makes the runtime inflate and
-// load that unit's code object.  launch_warm_tslab() touches all seven when TRILINEAR is selected (vr_set_filter /
+// load that unit's code object.  launch_warm_tslab() touches all ten when TRILINEAR is selected (vr_set_filter /
 // vr_load_shader), so neither the first TRILINEAR frame nor the first frame of a shape the measured choice tries pays it.
 #if VR_TSLAB_TU >= 0
 #define VR_TSLAB_CAT2(a, b) a##b
@@ -1335,6 +1365,9 @@ hipError_t launch_warm_tslab_tu3(hipStream_t st);
 hipError_t launch_warm_tslab_tu4(hipStream_t st);
 hipError_t launch_warm_tslab_tu5(hipStream_t st);
 hipError_t launch_warm_tslab_tu6(hipStream_t st);
+hipError_t launch_warm_tslab_tu7(hipStream_t st);
+hipError_t launch_warm_tslab_tu8(hipStream_t st);
+hipError_t launch_warm_tslab_tu9(hipStream_t st);
 hipError_t launch_warm_tslab(hipStream_t st)
 {
     hipError_t e = launch_warm_tslab_tu0(st);
@@ -1344,6 +1377,9 @@ hipError_t launch_warm_tslab(hipStream_t st)
     if (e == hipSuccess) e = launch_warm_tslab_tu4(st);
     if (e == hipSuccess) e = launch_warm_tslab_tu5(st);
     if (e == hipSuccess) e = launch_warm_tslab_tu6(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu7(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu8(st);
+    if (e == hipSuccess) e = launch_warm_tslab_tu9(st);
     return e;
 }
 #elif VR_TSLAB_TU == -1
