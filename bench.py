@@ -24,8 +24,10 @@ events on the launch stream.  `cpu_baseline` is the scalar oracle (oracle/vr_ora
 
 Set-up (untimed, like generating the volume) ends with --clock-ramp-frames frames (default
 150, ~75 ms): an idle MI355X reaches its sustained clocks only after ~50 ms of load, and the
-metric is the sustained rate of a renderer that is running.  Then W warm-up steps, a barrier,
-EXACTLY K timed steps, a barrier.  `config.clock_ramp_frames` records it; 0 switches it off.
+metric is the sustained rate of a renderer that is running; and with frames rendered one at a time until the
+measured launch choice of this configuration has settled (`config.settle_frames`; a handful when
+profiles/launch_choices.bin -- vr_import_choices -- already holds it).  Then W warm-up steps, a barrier,
+EXACTLY K timed steps, a barrier.  `config.clock_ramp_frames` records it; 0 switches both off.
 """
 from __future__ import annotations
 
@@ -75,10 +77,17 @@ def parse_args():
                     help="N > 1: gather the shards to rank 0 (default: the frame is needed in one place, like the reference's "
                          "single framebuffer; RCCL send/recv over rank 0's point-to-point links) or all_gather them to every rank")
     ap.add_argument("--pose", choices=("default", "offaxis"), default="default")
+    ap.add_argument("--mip", action="store_true", help="maximum intensity projection (VolumeRenderer.cs:141-173; RendererCore::setMIP)")
+    ap.add_argument("--view", choices=("front", "top", "bottom"), default="front",
+                    help="the reference's initial camera rotation (VolumeRenderer.cs:186-189; RendererCore::setInitialCameraRotation)")
     ap.add_argument("--kernel-variant", type=int, default=0, help="vr_set_kernel_variant (0 auto, 1 generic, 2 fast kernel with the plain loop, 3 always relay, 5 fast kernel with the pipelined loop)")
     ap.add_argument("--no-pack12", action="store_true", help="never gather from the 12-bit packed copy (vr_set_pack12(0))")
     ap.add_argument("--shard", type=int, nargs=2, default=None, metavar=("WORLD", "RANK"),
                     help="single process: time only the kernel of rank RANK's shard of a WORLD-GPU frame (no collective)")
+    ap.add_argument("--choices", default=str(ROOT / "profiles" / "launch_choices.bin"),
+                    help="blob of settled launch choices (vr_import_choices) loaded into every renderer of this run when it was measured by this build on "
+                         "this device model; 'none' = start cold")
+    ap.add_argument("--save-choices", action="store_true", help="write what this run's renderers settled on back to --choices (merged with what was imported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-stride", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     ap.add_argument("--extras", action="store_true",
@@ -273,9 +282,11 @@ def main():
 
     W, H, N, b = args.width, args.height, args.volume, args.bytes
     vmax = 4095 if b == 2 else 255
+    choices_load(args)
     r = vra.RendererCore(local_rank)
     r.setup((W, H))
     r.loadShader("VolumeRenderer.cs")
+    headline_choices_imported = choices_import(r)
     r.setQuirks(0)   # explicit window below is what the kernel sees (no +1000, no truncated grid)
     r.setLayout(R.LAYOUT_BRICKED if args.layout == "bricked" else R.LAYOUT_LINEAR)
     dims = tuple(args.dims) if args.dims else (N, N, N)
@@ -306,6 +317,9 @@ def main():
     r.setPack12(not args.no_pack12)
     r.setAlpha(args.alpha)
     r.setFilter(R.FILTER_TRILINEAR if args.filter == "trilinear" else R.FILTER_NEAREST)
+    r.setMIP(args.mip)
+    if args.view != "front":
+        r.setInitialCameraRotation(args.view == "top", args.view == "bottom")      # (also resets the camera, like the reference)
     if args.pose == "offaxis":
         r.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)   # zenith 60 deg, azimuth 45 deg
 
@@ -350,6 +364,7 @@ def main():
     total_samples = int(host_reduce([my_samples], "sum", torch.int64)[0])
 
     step_no = [0]
+    trial_frames = [0]                                   # launches that were a TRIAL of the measured choice (vr_get_launch_choice bit 8)
     root = 0 if (world > 1 and args.collective == "gather") else None
     # ---- RCCL preflight (untimed): the exact collective of a step, once, on a zero frame.  Every rank reports over the
     # host group whether it came back; if any did not, ALL ranks switch the shards to the host-staged gloo transport and
@@ -382,6 +397,7 @@ def main():
         r.renderAsync()
         if ev_pair:
             ev_pair[1].record(stream)
+            trial_frames[0] += (r.last_launch_choice >> 8) & 1
         if world == 1:
             return locals_[0][:H]
         ev_rendered[slot].record(stream)
@@ -402,6 +418,20 @@ def main():
     frame = None
     for _ in range(max(args.clock_ramp_frames, 0)):     # set-up: bring the GPU to its sustained clocks
         frame = step()
+    barrier()
+    # set-up, disclosed as config.settle_frames: the measured launch choice of a configuration this process has not seen (no
+    # imported entry) tries its candidates over the first frames and re-validates once 96 frames later; those frames are rendered
+    # HERE, one at a time, until 100 consecutive launches were the settled kernel (at most 400) -- the timed region below then
+    # contains no trial launches (config.trial_frames_in_timed_region counts them all the same)
+    settle_frames, quiet = 0, 0
+    if args.clock_ramp_frames > 0 and args.kernel_variant == 0:
+        need_quiet = 100 if headline_choices_imported == 0 else 3
+        # (N > 1: every step is a collective, so every rank renders the same fixed number of frames)
+        while settle_frames < (220 if need_quiet > 3 else 6) if world > 1 else (settle_frames < 400 and quiet < need_quiet):
+            frame = step()
+            torch.cuda.synchronize(dev)
+            quiet = 0 if (r.last_launch_choice >> 8) & 1 else quiet + 1
+            settle_frames += 1
     barrier()
     for _ in range(args.warmup):
         frame = step()
@@ -480,6 +510,11 @@ def main():
                 "kernel": r.last_kernel_name,
                 "voxel_dtype": "u%d" % (8 * b),
                 "clock_ramp_frames": max(args.clock_ramp_frames, 0),
+                "settle_frames": settle_frames,
+                # the measured launch choice: entries taken over from profiles/launch_choices.bin (vr_import_choices; 0 = this run
+                # explored its candidates itself during the untimed ramp) and how many of the TIMED launches were still trials
+                "launch_choices_imported": headline_choices_imported,
+                "trial_frames_in_timed_region": trial_frames[0],
             },
             "roofline": {
                 "bound": "hbm",
@@ -499,12 +534,26 @@ def main():
             # what binds, from counters where there are some: the vector L1's look-up rate when its PMC figure is there and
             # highest (round 5: removing 7 % of the loop's VALU issue cycles moved nothing, so "valu" -- a cost MODEL -- is only
             # named when no L1 figure contradicts it)
-            cands = {"hbm": result["roofline"]["frac"]}
+            # every candidate with the KIND of evidence behind it (round-5 verdict: an argmax over unlike fractions proves nothing):
+            bounds = [{"name": "hbm", "frac": result["roofline"]["frac"],
+                       "kind": "measured kernel time against the metric's algorithmic bytes at the datasheet peak (8 TB/s)"}]
             if rv.get("frac") is not None:
-                cands["valu (modelled)"] = rv["frac"]
+                bounds.append({"name": "valu issue", "frac": rv["frac"],
+                               "kind": "MODELLED: counted wave-instructions (PMC pass of this command) x per-instruction issue costs from a micro-benchmark"})
             if (rv.get("l1_rate") or {}).get("frac") is not None:
-                cands["vector L1 look-up rate (measured)"] = rv["l1_rate"]["frac"]
-            result["binding_bound"] = max(cands, key=cands.get)
+                bounds.append({"name": "vector L1 look-up rate", "frac": rv["l1_rate"]["frac"],
+                               "kind": "MEASURED counter (TCP_TOTAL_CACHE_ACCESSES per CU per shader cycle) against a capacity of ~1 per cycle measured by tools/ubench/tcp_rate.hip"})
+            result["bounds"] = bounds
+            # what binds: a measured counter at or near its capacity (>= 0.9) is named; a modelled fraction is only named when no
+            # measured one reaches that, and says so
+            measured = [b_ for b_ in bounds[1:] if b_["kind"].startswith("MEASURED") and b_["frac"] >= 0.9]
+            if measured:
+                result["binding_bound"] = max(measured, key=lambda b_: b_["frac"])["name"] + " (measured counter)"
+            elif len(bounds) > 1:
+                top = max(bounds, key=lambda b_: b_["frac"])
+                result["binding_bound"] = top["name"] + (" (modelled)" if top["kind"].startswith("MODELLED") else "")
+            else:
+                result["binding_bound"] = "hbm (no counter pass committed for these sources)"
         if world == 1:
             # the box's own achievable HBM read rate (streaming read of the resident volume),
             # measured after the timed region ("confirm the peak on the box")
@@ -532,6 +581,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, r, frame, value)
         if world == 1 and not args.no_extras and not args.shard:
             result["extras"] = extras(args, r, local, stream, b, W, H)
+    choices_collect(r)
     if rank == 0 and world == 1 and not args.no_extras and not args.shard and not args.dataset and args.volume == 1024 and not args.dims:
         # the other BASELINE configs (1, 2, 4), each on its own renderer; the headline's volume is released first
         r.close()
@@ -543,8 +593,67 @@ def main():
         dist.barrier(group=host_pg)
         dist.destroy_process_group()
     r.close()
+    if rank == 0 and args.save_choices and args.choices and args.choices != "none":
+        merged = choices_merge([CHOICES["blob"]] + CHOICES["exported"])
+        if merged:
+            Path(args.choices).write_bytes(merged)
+            print(f"[bench] {len(merged)} bytes of settled launch choices written to {args.choices}", file=sys.stderr)
     if result is not None:
         print(json.dumps(result), flush=True)
+
+
+CHOICES = {"blob": None, "imported": 0, "exported": []}
+
+
+def choices_load(args):
+    """the committed blob of settled launch choices (profiles/launch_choices.bin), if any"""
+    if args.choices and args.choices != "none" and Path(args.choices).is_file():
+        CHOICES["blob"] = Path(args.choices).read_bytes()
+
+
+def choices_import(r):
+    """give renderer r what an earlier run measured (only accepted from the same library build on the same device model)"""
+    if CHOICES["blob"]:
+        try:
+            n = r.importChoices(CHOICES["blob"])
+            CHOICES["imported"] += n
+            return n
+        except Exception as exc:                              # a stale / foreign file never costs the run
+            print(f"[bench] launch choices not imported: {exc}", file=sys.stderr)
+    return 0
+
+
+def choices_collect(r):
+    try:
+        CHOICES["exported"].append(r.exportChoices())
+    except Exception as exc:
+        print(f"[bench] launch choices not exported: {exc}", file=sys.stderr)
+
+
+def choices_merge(blobs):
+    """union by key of blobs with the same header (88-byte header, 56-byte records: csrc/renderer_core.cpp ChoiceHeader / ChoiceRecord); later blobs win"""
+    import struct
+
+    head, recs = None, {}
+    for b in blobs:
+        if not b or len(b) < 88 or b[:8] != b"VRCHOICE":
+            continue
+        h = bytearray(b[:88])
+        ident = bytes(h[:12]) + bytes(h[16:])                 # everything but the count
+        if head is None:
+            head = (ident, h)
+        elif head[0] != ident:
+            continue
+        n = struct.unpack_from("<I", b, 12)[0]
+        for i in range(n):
+            rec = b[88 + 56 * i: 88 + 56 * (i + 1)]
+            if len(rec) == 56:
+                recs[rec[:8]] = rec
+    if head is None:
+        return b""
+    h = head[1]
+    struct.pack_into("<I", h, 12, len(recs))
+    return bytes(h) + b"".join(recs.values())
 
 
 def plan_pixels(plan, W):
@@ -567,7 +676,7 @@ def kernel_source_hash() -> str:
 
 def headline_key(args):
     """key of this command in profiles/traffic.json / valu.json, or None for commands that have no committed PMC pass"""
-    if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12 or args.synth != "noise_ball":
+    if args.dims or args.window or args.tf or args.skip_empty or args.pose != "default" or args.dataset or args.no_pack12 or args.synth != "noise_ball" or args.mip or args.view != "front":
         return None
     return f"{args.volume}^3x{args.bytes}B_{args.width}x{args.height}_{args.filter}_{args.layout}_a{args.alpha}"
 
@@ -597,7 +706,8 @@ def cpu_baseline(args, r, frame, gpu_msamples):
     gpu = frame.cpu().numpy()
 
     def run(rows, threads):
-        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1],
+        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1], is_mip=int(args.mip),
+                                view_top=int(args.view == "top"), view_bottom=int(args.view == "bottom"),
                                 filter=1 if args.filter == "trilinear" else 0, threads=threads, tf_rgba=tf)
         out = np.zeros((H, W, 4), dtype=np.float32)
         samples, secs = 0, 0.0
@@ -630,7 +740,8 @@ def cpu_baseline(args, r, frame, gpu_msamples):
         per_row = max(ps / len(probe_rows), 1.0)
         nrows = int(min(H, max(cores, rate * cores * 5.0 / per_row)))
         y0 = max(0, H // 2 - nrows // 2)
-        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1],
+        p = oracle.OracleParams(W, H, cam=cam, alpha_scale=args.alpha, min_val=win[0], max_val=win[1], is_mip=int(args.mip),
+                                view_top=int(args.view == "top"), view_bottom=int(args.view == "bottom"),
                                 filter=1 if args.filter == "trilinear" else 0, threads=cores, tf_rgba=tf)
         p.row_begin, p.row_end = y0, min(H, y0 + nrows)
         out2 = np.zeros((H, W, 4), dtype=np.float32)
@@ -670,9 +781,6 @@ def traffic_entry(key, kernel):
     return None
 
 
-VALU_FAMILY = {"raymarch_slab_tri_kernel": "raymarch_tslab_kernel"}
-
-
 def valu_roofline(key, kernel, kernel_ms):
     """VALU-issue fraction of one configuration: measured wave-instructions (profiles/valu.json: SQ_INSTS_VALU and the
     launch's shader cycles, tools/pmc_valu.py) x the cost per instruction of the kernel family's hot loops
@@ -684,7 +792,7 @@ def valu_roofline(key, kernel, kernel_ms):
         cpi_all = json.loads((ROOT / "profiles" / "valu_cpi.json").read_text())
         if not isinstance(v, dict) or v.get("kernel") != kernel or v.get("kernel_source_hash") != kernel_source_hash():
             return None
-        fam = VALU_FAMILY.get(kernel, kernel)
+        fam = kernel
         if fam == "raymarch_tslab_kernel" and ", true>" in v.get("instance", ""):
             fam = "raymarch_tslab_kernel_half"
         cpi = cpi_all["families"][fam]["cpi"]
@@ -771,10 +879,20 @@ def config_extras(device):
         fv = (out[name]["roofline_valu"] or {}).get("frac")
         out[name]["bound"] = "valu" if fv is not None and fv > out[name]["roofline_frac"] else "hbm"
 
-    def renderer(W, H):
-        r = vra.RendererCore(device)
-        r.setup((W, H)); r.loadShader("VolumeRenderer.cs"); r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED)
-        return r
+    class renderer:
+        """a renderer per configuration that starts on the imported launch choices and hands back what it settled on"""
+
+        def __init__(self, W, H):
+            self.r = vra.RendererCore(device)
+            self.r.setup((W, H)); self.r.loadShader("VolumeRenderer.cs"); self.r.setQuirks(0); self.r.setLayout(R.LAYOUT_BRICKED)
+            choices_import(self.r)
+
+        def __enter__(self):
+            return self.r
+
+        def __exit__(self, *exc):
+            choices_collect(self.r)
+            self.r.close()
 
     with renderer(1280, 720) as r:
         f = os.environ.get("VR_DATA_BONSAI")
@@ -824,7 +942,11 @@ def config_extras(device):
         r.setFilter(R.FILTER_TRILINEAR)                      # 10 GiB apron copy next to the 8 GiB volume; the LDS-staged kernel (64-bit DMA addresses)
         timed(r, "cfg4_grey_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, filter=1)
         out["cfg4_grey_trilinear"]["apron_copy_bytes"] = r.trilinearCopyBytes()
+        r.setMIP(True)                                       # the reference's second mode at config 4's size, both filters
+        timed(r, "cfg4_mip_trilinear", 1, 3840, 2160, 5, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, filter=1, is_mip=1)
         r.setFilter(R.FILTER_NEAREST)
+        timed(r, "cfg4_mip", 1, 3840, 2160, 10, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, is_mip=1)
+        r.setMIP(False)
         r.setTransferFunction([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
         r.setSkipEmpty(True)
         timed(r, "cfg4_tf_skip", 1, 3840, 2160, 10, vol=vol, alpha_scale=0.004, min_val=8, max_val=255, tf_rgba=r.getTransferLut())
@@ -863,7 +985,8 @@ def extras(args, r, local, stream, b, W, H):
         vmax = 4095 if b == 2 else 255
         win = tuple(args.window) if args.window else (0, vmax)
         kw = dict(vol=vol_host[0], alpha_scale=args.alpha, min_val=win[0], max_val=win[1], filter=1 if args.filter == "trilinear" else 0,
-                  tf_rgba=r.getTransferLut() if args.tf else None)
+                  tf_rgba=r.getTransferLut() if args.tf else None, is_mip=int(args.mip), view_top=int(args.view == "top"),
+                  view_bottom=int(args.view == "bottom"))
         kw.update(okw)
         ok, diff = sparse_row_parity(r, [H // 4 + 3, H // 2, (3 * H) // 4 - 5], **kw)
         r.setFramebufferExternal(local.data_ptr()); r.setFramebufferCompact(True)
@@ -930,6 +1053,20 @@ def extras(args, r, local, stream, b, W, H):
             r.setFilter(R.FILTER_TRILINEAR)
             timed("trilinear_offaxis_deep", steps=10, filter=1)      # oblique view: half layers of the staged kernel (round 3: the batched kernel)
             r.setFilter(R.FILTER_NEAREST)
+        r.resetCamera()
+    if args.pose == "default" and not args.mip and args.view == "front":
+        # the reference's other modes at size (round-5 verdict): MIP (VolumeRenderer.cs:141-173) and the two rotated views
+        # (:186-189; src/RendererCore.cpp:84-98 -- they permute the volume axes the rays advance along in memory), NEAREST and TRILINEAR
+        for name, setup, okw in (("mip_deep", lambda: r.setMIP(True), dict(is_mip=1)),
+                                 ("view_top_deep", lambda: r.setInitialCameraRotation(True, False), dict(view_top=1)),
+                                 ("view_bottom_deep", lambda: r.setInitialCameraRotation(False, True), dict(view_bottom=1))):
+            setup()
+            timed(name if args.filter == "nearest" else "trilinear_" + name, **okw)
+            if args.filter == "nearest":
+                r.setFilter(R.FILTER_TRILINEAR)
+                timed("trilinear_" + name, steps=10, filter=1, **okw)
+                r.setFilter(R.FILTER_NEAREST)
+            r.setMIP(False); r.setInitialCameraRotation(False, False)
         r.resetCamera()
     if args.extras:
         # interactive use: the camera moves every frame (GUI orbit), host work included (wall clock)

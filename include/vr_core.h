@@ -193,6 +193,14 @@ int vr_set_autotune(vr_handle h, int enable);
    vr_set_kernel_variant 6 .. 11 minus 5), bit 8 (256): the measured choice is still EXPLORING this configuration -- the
    frame was a trial of one candidate (up to ~45 % slower than the settled choice), not the settled kernel */
 int vr_get_launch_choice(vr_handle h);
+/* The SETTLED entries of the measured choice as a flat blob, and back (round 6).  The reference dispatches one shader per frame and
+   never tries anything (src/RendererCore.cpp:138-163); a handle that imports what another handle or an earlier process measured does
+   the same for every configuration the blob knows: frame 1 runs on the settled kernel, no trial frames, no re-validation.
+   vr_export_choices: *bytes = the size the blob needs (call with buf NULL to ask); it is written when capacity suffices, else VR_E_INVALID.
+   vr_import_choices: *accepted = entries taken over; a blob measured on another device model or by another build of the library is
+   well-formed but not trusted: 0 entries, VR_OK.  Malformed blobs: VR_E_INVALID. */
+int vr_export_choices(vr_handle h, void *buf, size_t capacity, size_t *bytes);
+int vr_import_choices(vr_handle h, const void *buf, size_t bytes, int *accepted);
 /* 1 (default): when every voxel of a bricked 16-bit volume is <= 4095 (12-bit data) the
    specialised kernel gathers from a lossless 12-bit packed copy kept beside the volume (25 %
    fewer cache lines per frame; frames are bit-identical); 0: never.  Build-defined. */

@@ -237,3 +237,17 @@ def test_file_parsers_survive_mutated_inputs_under_sanitizers(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1")
     run = subprocess.run([str(exe), "4000"] + seeds, capture_output=True, text=True, env=env, timeout=300, cwd=str(tmp_path))
     assert run.returncode == 0 and "no crash" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
+
+
+def test_choices_blob_roundtrip_without_a_device(vra):
+    """vr_export_choices / vr_import_choices on a handle without a device: an empty table is an 88-byte header, it imports
+    back (0 entries), and malformed blobs are refused with VR_E_INVALID"""
+    r = vra.RendererCore(-1)
+    blob = r.exportChoices()
+    assert len(blob) == 88 and blob[:8] == b"VRCHOICE"
+    assert r.importChoices(blob) == 0
+    for bad in (b"", b"VRCHOICE", b"XXCHOICE" + blob[8:], blob[:87]):
+        with pytest.raises(vra.VRError) as e:
+            r.importChoices(bad)
+        assert e.value.code == vra.renderer.VR_E_INVALID
+    r.close()

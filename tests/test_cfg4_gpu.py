@@ -189,7 +189,7 @@ def test_cfg4_trilinear_staged_kernel_beyond_4gib(vra, oracle, cfg4, cfg4_host_v
                 for _ in range(2):
                     r.render()
                 ms[name] = r.kernelMsTake() / 2
-                assert r.last_kernel_name == ("raymarch_slab_tri_kernel" if name == "staged" else "raymarch_generic_kernel"), (name, r.last_kernel_name)
+                assert r.last_kernel_name == ("raymarch_tslab_kernel" if name == "staged" else "raymarch_generic_kernel"), (name, r.last_kernel_name)
                 frames[name] = r.readPixels().copy()
                 counts[name] = r.countSamples()
             print(f"cfg4 trilinear tf={tf}: staged {ms['staged']:.3f} ms, generic {ms['generic']:.3f} ms, apron copy {r.trilinearCopyBytes() / 2**30:.1f} GiB")
@@ -223,7 +223,7 @@ def test_cfg4_trilinear_staged_kernel_beyond_4gib(vra, oracle, cfg4, cfg4_host_v
             for ci, block in enumerate(cams):
                 r.setCameraBlock(block)
                 r.render()
-                assert r.last_kernel_name == "raymarch_slab_tri_kernel", (mode, ci)
+                assert r.last_kernel_name == "raymarch_tslab_kernel", (mode, ci)
                 got = r.readPixels()
                 total, spp = r.countSamples(per_pixel=True)
                 p = oracle.OracleParams(w, h, cam=block, alpha_scale=alpha, min_val=WINDOW[0], max_val=WINDOW[1], is_mip=int(mip), tf_rgba=lut, filter=1, threads=8)

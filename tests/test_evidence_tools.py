@@ -81,13 +81,13 @@ def test_traffic_is_attributed_to_the_kernel_the_bench_line_names(sandbox):
     # the bench line's alias for the staged trilinear kernel
     out3 = sandbox / "prof3"
     out3.mkdir()
-    (out3 / "a.log").write_text('{"config": {"kernel": "raymarch_slab_tri_kernel"}}\n')
+    (out3 / "a.log").write_text('{"config": {"kernel": "raymarch_tslab_kernel"}}\n')
     for c, v in (("FETCH_SIZE", 1700.0), ("WRITE_SIZE", 30.0), ("SQ_INSTS_VALU", 8.0e8), ("GRBM_GUI_ACTIVE", 2.4e7)):
         write_pass(out3, c, [(TSLAB, 100, v), ("void vr::raymarch_tri_kernel<unsigned short, 1, 0, 0, true, 0, true>(vr::FrameParams)", 8, v * 3)])
     assert run("pmc_traffic.py", out3, "unit_test_key3", profiles=sandbox).returncode == 0
     assert run("pmc_valu.py", out3, "unit_test_key3", profiles=sandbox).returncode == 0
     v = json.loads((ROOT / "profiles" / "valu.json").read_text())["unit_test_key3"]
-    assert v["kernel"] == "raymarch_slab_tri_kernel" and v["valu_wave_insts"] == 8.0e8 and v["shader_cycles"] == 2.4e7 / 8
+    assert v["kernel"] == "raymarch_tslab_kernel" and v["valu_wave_insts"] == 8.0e8 and v["shader_cycles"] == 2.4e7 / 8
 
 
 def test_bench_refuses_a_figure_of_another_kernel_or_of_other_sources(sandbox):

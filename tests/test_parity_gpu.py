@@ -770,7 +770,7 @@ def test_long_axis_volume_without_address_tables(vra, oracle):
             want, _, want_spp = oracle.render(vol, p, want_spp=True)
             assert_same(got, want, spp, want_spp, what=f"long-axis volume layout {layout} filter {filt} mip {mip} kernel {kernel}")
             if filt == R.FILTER_TRILINEAR:       # bricked: the LDS-staged kernel's plan and tables cover a tile's own index ranges only (round 3)
-                assert kernel == ("raymarch_slab_tri_kernel" if layout == R.LAYOUT_BRICKED else "raymarch_generic_kernel")
+                assert kernel == ("raymarch_tslab_kernel" if layout == R.LAYOUT_BRICKED else "raymarch_generic_kernel")
             else:
                 assert kernel in FAST_KERNELS
 
@@ -817,7 +817,7 @@ def test_trilinear_kernel_full_size_equals_generic(vra, cfg3):
             b = r.readPixels().copy()
             nb = r.countSamples()
             # automatic choice at the (axis-aligned) default pose: the LDS-staged kernel; variant 2: the batched kernel
-            for variant, name in ((0, "raymarch_slab_tri_kernel"), (2, "raymarch_tri_kernel")):
+            for variant, name in ((0, "raymarch_tslab_kernel"), (2, "raymarch_tri_kernel")):
                 r.setKernelVariant(variant); r.render()
                 assert r.last_kernel_name == name
                 a = r.readPixels().copy()

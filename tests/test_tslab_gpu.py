@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TSLAB = "raymarch_slab_tri_kernel"
+TSLAB = "raymarch_tslab_kernel"
 
 
 def bits(a):

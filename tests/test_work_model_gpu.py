@@ -69,3 +69,49 @@ def test_a_slider_drag_does_not_keep_the_model_exploring(vra):
         off = sum(1 for c in seen[40:] if c != final)
         assert off <= 16, (final, off, seen[:60])                # one exploration per bucket crossed at most, not one per frame
         assert len(set(seen[-60:])) == 1
+
+
+def test_imported_choices_start_a_cold_handle_on_the_settled_kernel(vra):
+    """vr_export_choices / vr_import_choices (round 6): what one handle measured, a new handle -- here standing in for a new
+    process -- starts on: frame 1 is the settled kernel, no frame is a trial (bit 8 of vr_get_launch_choice), and the frames
+    are the same bits.  A blob from another build / device is well-formed but takes over nothing; a mangled one is refused.
+    The reference never tries anything: one dispatch per frame (src/RendererCore.cpp:138-163)."""
+    R = vra.renderer
+
+    def fresh():
+        r = vra.RendererCore(0)
+        r.setup((1920, 1080)); assert r.loadShader("VolumeRenderer.cs"); r.setQuirks(0)
+        r.generateSynthetic(R.SYNTH_NOISE_BALL, (512, 512, 512), 2, 0x9E3779B9); r.setWindow(0, 4095); r.setAlpha(0.004)
+        r.setRowStripes(16, 3, 8)                               # a sparse shard: relay against fast kernel, a real choice
+        return r
+
+    with fresh() as a:
+        for _ in range(300):
+            a.render()
+        settled = a.last_launch_choice
+        assert settled & 256 == 0
+        want = a.readPixels().copy()
+        blob = a.exportChoices()
+        assert blob[:8] == b"VRCHOICE" and len(blob) >= 88 + 56
+    with fresh() as b:
+        assert b.importChoices(blob) >= 1
+        trials, choices = 0, set()
+        for _ in range(40):
+            b.render()
+            trials += (b.last_launch_choice >> 8) & 1
+            choices.add(b.last_launch_choice)
+        assert trials == 0 and choices == {settled}, (trials, choices, settled)
+        assert np.array_equal(b.readPixels().view(np.uint32), want.view(np.uint32))
+        # another build's blob: same layout, other build id -> nothing taken over
+        foreign = bytearray(blob); foreign[16] ^= 0x5a
+        assert b.importChoices(bytes(foreign)) == 0
+        with pytest.raises(vra.VRError):
+            b.importChoices(b"VRCHOICX" + blob[8:])
+        with pytest.raises(vra.VRError):
+            b.importChoices(blob[:100])
+    with fresh() as c:                                           # the control: without the blob the first frames do explore
+        trials = 0
+        for _ in range(12):
+            c.render()
+            trials += (c.last_launch_choice >> 8) & 1
+        assert trials > 0

@@ -31,8 +31,6 @@ import sys
 from collections import defaultdict
 from pathlib import Path
 
-# bench.py's `config.kernel` -> the kernel's symbol
-ALIAS = {"raymarch_slab_tri_kernel": "raymarch_tslab_kernel"}
 
 
 def kernel_from_logs(out):
@@ -57,7 +55,6 @@ def per_kernel(out, counter):
     return acc
 
 
-REV = {v: k for k, v in ALIAS.items()}
 
 
 def settled(acc, family, key, counter):
@@ -65,7 +62,7 @@ def settled(acc, family, key, counter):
     instance of `family` when it has at least a third of the run's ray-march launches; otherwise -- the JSON line names the LAST
     launch's kernel, which under the profiler can be one of the work model's re-measurements -- the instance with more than half
     of the launches, whatever its family; otherwise none (exit)"""
-    symbol = ALIAS.get(family, family)
+    symbol = family            # bench.py's `config.kernel` IS the kernel's symbol (vr_last_kernel_name)
     march = {k: v for k, v in acc.items() if "raymarch_" in k}
     total = sum(len(v) for v in march.values())
     mine = {k: v for k, v in march.items() if re.search(r"\b" + re.escape(symbol) + r"\b", k)}
@@ -75,7 +72,7 @@ def settled(acc, family, key, counter):
     top = max(march, key=lambda k: len(march[k])) if march else None
     if top is not None and 2 * len(march[top]) > total:
         sym = re.search(r"(raymarch_\w+)", top).group(1)
-        return REV.get(sym, sym), top, march[top], total
+        return sym, top, march[top], total
     if name is None:
         sys.exit(f"{key}: no launches of {symbol} in the {counter} pass ({sorted(march)})")
     sys.exit(f"{key}: the most-launched {symbol} instance has {len(mine[name])} of {total} ray-march launches in the {counter} pass -- not the settled kernel")

@@ -805,6 +805,84 @@ void RendererCore::tuneCollect()
     }
 }
 
+// ---- settled choices as a blob.  The reference dispatches ONE shader per frame and never tries anything
+// (src/RendererCore.cpp:138-163); with an imported table neither does this library for the configurations the table knows.
+#ifndef VR_BUILD_ID
+#define VR_BUILD_ID 0ull
+#endif
+namespace {
+struct ChoiceHeader { char magic[8]; uint32_t version, count; uint64_t build_id; char device[64]; };
+struct ChoiceRecord { uint64_t key; int32_t ncand, settled_value, heur, cand[8]; };
+static_assert(sizeof(ChoiceHeader) == 88 && sizeof(ChoiceRecord) == 56, "blob layout");
+void choiceDeviceName(int device, char (&out)[64])
+{
+    std::memset(out, 0, sizeof(out));
+    if (device < 0) return;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::strncpy(out, prop.name, sizeof(out) - 1);
+}
+}  // namespace
+
+size_t RendererCore::exportChoices(void *buf, size_t capacity)
+{
+    static_assert(kTuneCand == 8, "ChoiceRecord::cand");
+    tuneCollect();                                                       // measurements whose events have completed since the last launch count
+    uint32_t n = 0;
+    for (const auto &kv : tune_) if (kv.second.settled >= 0) n++;
+    const size_t need = sizeof(ChoiceHeader) + (size_t)n * sizeof(ChoiceRecord);
+    if (!buf || capacity < need) return need;
+    ChoiceHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "VRCHOICE", 8);
+    h.version = 1; h.count = n; h.build_id = (uint64_t)VR_BUILD_ID;
+    choiceDeviceName(device_, h.device);
+    std::memcpy(buf, &h, sizeof(h));
+    char *q = static_cast<char *>(buf) + sizeof(h);
+    for (const auto &kv : tune_) {
+        const TuneEntry &e = kv.second;
+        if (e.settled < 0) continue;
+        ChoiceRecord r;
+        std::memset(&r, 0, sizeof(r));
+        r.key = kv.first; r.ncand = e.ncand; r.settled_value = e.cand[e.settled]; r.heur = e.heur;
+        for (int c = 0; c < e.ncand; c++) r.cand[c] = e.cand[c];
+        std::memcpy(q, &r, sizeof(r));
+        q += sizeof(r);
+    }
+    return need;
+}
+
+int RendererCore::importChoices(const void *buf, size_t bytes)
+{
+    if (!buf || bytes < sizeof(ChoiceHeader)) throw std::invalid_argument("importChoices: blob too short");
+    ChoiceHeader h;
+    std::memcpy(&h, buf, sizeof(h));
+    if (std::memcmp(h.magic, "VRCHOICE", 8) != 0 || h.version != 1) throw std::invalid_argument("importChoices: not a choices blob of this library");
+    if (bytes < sizeof(h) + (size_t)h.count * sizeof(ChoiceRecord)) throw std::invalid_argument("importChoices: truncated blob");
+    char mine[64];
+    choiceDeviceName(device_, mine);
+    if (h.build_id != (uint64_t)VR_BUILD_ID || std::memcmp(h.device, mine, sizeof(mine)) != 0) return 0;   // measured elsewhere: not trusted
+    const char *q = static_cast<const char *>(buf) + sizeof(h);
+    int accepted = 0;
+    for (uint32_t i = 0; i < h.count && tune_.size() < (size_t)kTuneEntries; i++, q += sizeof(ChoiceRecord)) {
+        ChoiceRecord r;
+        std::memcpy(&r, q, sizeof(r));
+        if (r.ncand < 2 || r.ncand > kTuneCand) continue;
+        int settled = -1;
+        for (int c = 0; c < r.ncand; c++) if (r.cand[c] == r.settled_value) settled = c;
+        if (settled < 0) continue;
+        TuneEntry e;
+        e.ncand = r.ncand; e.heur = r.heur; e.settled = settled;
+        for (int c = 0; c < r.ncand; c++) { e.cand[c] = r.cand[c]; e.tries[c] = e.issued[c] = kTuneTries; }
+        e.revalidated = true;                                            // it was measured at sustained clocks where it came from
+        e.last_use = tune_clock_;
+        e.gen = ++tune_gen_counter_;
+        tune_[r.key] = e;
+        accepted++;
+    }
+    return accepted;
+}
+
 void RendererCore::tuneChoose(const FrameParams &P, LaunchConfig &L)
 {
     tune_measure_ = false;

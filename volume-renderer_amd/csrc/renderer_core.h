@@ -98,6 +98,11 @@ public:
     double measureStreamRead(int reps);
     void assembleShards(const void *gathered, void *frame, int n, int local_rows, int stripe_rows, int channels, void *hip_stream);
     const char *lastKernelName() const { return last_kernel_; }
+    // settled entries of the measured work model as a flat blob (vr_export_choices / vr_import_choices): a handle that imports what
+    // another handle -- or an earlier process -- measured starts every known configuration on its settled kernel, with no trial frames.
+    // A blob is only accepted on the device model and library build it was measured with (returns 0 entries otherwise).
+    size_t exportChoices(void *buf, size_t capacity);           // bytes the blob needs; written when capacity suffices
+    int importChoices(const void *buf, size_t bytes);           // entries accepted
     int lastLaunchChoice() const { return last_choice_; }     // 1 relay, 2 pipelined loop, 4 short batches, tri_slab << 3, 256: the work model is still exploring this configuration
     size_t lastPacked12Bytes() const { return last_packed12_bytes_; }
     size_t lastApronBytes() const { return last_apron_bytes_; }

@@ -109,7 +109,9 @@ unsigned buildTileSchedule(const FrameParams &P, int rows, std::vector<uint32_t>
     const unsigned tiles_y = (unsigned)((rows + (int)tile_h - 1) / (int)tile_h);
     // a chunk = CW x CH neighbouring tiles that go to one XCD.  Measured on cfg3 (1x1 ... 16x4):
     // single tiles win -- balance across the XCDs matters more than sharing brick rows in one
-    // L2 (0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4).
+    // L2 (round 1: 0.59 ms vs 0.62 ms for 4x1, 0.69 ms for 16x4; re-measured in round 6 on the packed, pipelined kernel with
+    // L2 counters, chunks and one compact equal-work region per XCD: 0.461 ms vs 0.465-0.498, HBM reads only 9 % lower at
+    // best -- profiles/r06_xcd_ownership.txt).
     unsigned CW = kFastChunkW, CH = kFastChunkH;
     if (P.stripe_count > 1) CH = 1;          // cyclic stripes: vertically adjacent local tiles are not neighbours
     const unsigned cpr = (tiles_x + CW - 1) / CW, cpc = (tiles_y + CH - 1) / CH, per_chunk = CW * CH;

@@ -551,6 +551,23 @@ unsigned int vr_checksum(const unsigned char *data, unsigned int bytes)
 
 void vr_free(void *p) { std::free(p); }
 
+int vr_export_choices(vr_handle h, void *buf, size_t capacity, size_t *bytes)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        const size_t need = c.exportChoices(buf, capacity);
+        if (bytes) *bytes = need;
+        if (buf && capacity < need) throw std::invalid_argument("vr_export_choices: buffer too small");
+    });
+}
+
+int vr_import_choices(vr_handle h, const void *buf, size_t bytes, int *accepted)
+{
+    return guarded(h, [&](vr::RendererCore &c) {
+        const int n = c.importChoices(buf, bytes);
+        if (accepted) *accepted = n;
+    });
+}
+
 int vr_get_launch_choice(vr_handle h) { return h ? h->core.lastLaunchChoice() : 0; }
 const char *vr_last_kernel_name(vr_handle h) { return h ? h->core.lastKernelName() : ""; }
 

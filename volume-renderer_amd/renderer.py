@@ -118,6 +118,8 @@ def load_library() -> C.CDLL:
         "vr_set_skip_empty": (i32, [h, i32]),
         "vr_set_kernel_variant": (i32, [h, i32]),
         "vr_set_autotune": (i32, [h, i32]),
+        "vr_export_choices": (i32, [h, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "vr_import_choices": (i32, [h, C.c_void_p, C.c_size_t, C.POINTER(i32)]),
         "vr_get_launch_choice": (i32, [h]),
         "vr_get_resident_bytes": (i32, [h, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "vr_set_copy_budget": (i32, [h, C.c_uint64]),
@@ -502,6 +504,21 @@ class RendererCore:
 
     def setKernelVariant(self, variant):
         self._check(self._lib.vr_set_kernel_variant(self._h, variant))
+
+    def exportChoices(self) -> bytes:
+        """settled entries of the measured launch choice (vr_export_choices)"""
+        n = C.c_size_t(0)
+        self._check(self._lib.vr_export_choices(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._check(self._lib.vr_export_choices(self._h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def importChoices(self, blob: bytes) -> int:
+        """entries accepted (0: measured on another device model / library build)"""
+        acc = C.c_int(0)
+        buf = C.create_string_buffer(bytes(blob), len(blob))
+        self._check(self._lib.vr_import_choices(self._h, buf, len(blob), C.byref(acc)))
+        return acc.value
 
     def setAutotune(self, on):
         """kernel variant 0: measure the candidate kernels on the first frames of a configuration and keep the fastest (default on)"""
