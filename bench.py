@@ -250,16 +250,43 @@ def main():
 
         backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
         if backend == "nccl":
+            # The nccl -> gloo fallback must be ONE decision for the whole job (round-5 advisor: decided per rank, a partial
+            # failure left ranks in different default groups until the 180 s timeout).  The ranks of this single-node job agree
+            # through marker files keyed by the rendezvous port: every rank reports whether its init came back, waits for all
+            # reports, and if any failed, EVERY rank drops to gloo.
+            import glob
+            import tempfile
+            tag = os.path.join(tempfile.gettempdir(), f"vr_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}")
+            ok, why = True, ""
             try:
-                if os.environ.get("VR_BENCH_FAIL_NCCL_INIT"):
+                fail_hook = os.environ.get("VR_BENCH_FAIL_NCCL_INIT")
+                if fail_hook and (fail_hook == "1" or str(rank) in fail_hook.split(",")):
                     raise RuntimeError("VR_BENCH_FAIL_NCCL_INIT (test hook)")
                 dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=180))
-            except Exception as exc:      # RCCL unusable on this node: the shards travel over gloo, and the line says so
-                init_fallback = repr(exc)[:200]
-                print(f"[bench] rank {rank}: nccl backend failed to initialise ({init_fallback}); continuing on gloo", file=sys.stderr)
+            except Exception as exc:
+                ok, why = False, repr(exc)[:200]
+            Path(f"{tag}_rank{rank}.{'ok' if ok else 'fail'}").write_text(why)
+            t_wait, files = time.perf_counter(), []
+            while True:                                                  # ONE snapshot decides, the same on every rank
+                files = sorted(glob.glob(f"{tag}_rank*.*"))
+                if len(files) >= world or time.perf_counter() - t_wait > 200.0:
+                    break
+                time.sleep(0.05)
+            failed = [f for f in files if f.endswith(".fail")]
+            if failed or len(files) < world:                             # RCCL unusable somewhere: the shards travel over gloo, and the line says so
+                init_fallback = (why or ("rank " + failed[0].rsplit("_rank", 1)[1].split(".")[0] + " failed its nccl init" if failed
+                                         else "a rank never reported its nccl init"))[:200]
+                print(f"[bench] rank {rank}: nccl backend unusable on this job ({init_fallback}); every rank continues on gloo", file=sys.stderr)
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 dist.init_process_group("gloo", timeout=timedelta(seconds=180))
+            dist.barrier()                                               # every rank has read the markers
+            if rank == 0:
+                for f in files:
+                    try:
+                        os.unlink(f)
+                    except OSError:
+                        pass
         else:
             dist.init_process_group(backend)
         # a host-side group next to RCCL: bookkeeping reductions (sample totals, timings, flags) and -- if the RCCL

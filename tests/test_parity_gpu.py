@@ -1134,6 +1134,46 @@ def test_relay_kernel_modes_and_views(vra, oracle, dtype, mode):
                     assert_same(got, want, spp, want_spp, what=f"relay {mode} {dims} {np.dtype(dtype).name} layout {layout} {name}")
 
 
+def test_grey_transfer_function_folded_into_the_grey_ramp_table(vra, oracle):
+    """round-5 advisor: a GREY transfer function under NEAREST composite is folded into the grey-ramp instances' (c, a) table
+    (FrameParams::tf_grey) -- on the fast kernel, on the relay kernel, and through the 12-bit packed copy of CT-style data whose
+    minimum is 1000 (pk12_base): every one of them must equal the transfer-function kernel proper (generic, variant 1) and the
+    oracle bit for bit; with TRILINEAR the flag must stay off (the staged kernel classifies through the RGBA table)."""
+    R = vra.renderer
+    knots = ([0, 141, 149, 255], [[0, 0, 0, 0], [0.55, 0.55, 0.55, 0.759], [0.58, 0.58, 0.58, 0.45], [1, 1, 1, 1]])
+    for synth, dims, b, win in ((R.SYNTH_NOISE_BALL_CT, (160, 144, 128), 2, (1000, 5095)), (R.SYNTH_NOISE_BALL, (128, 128, 128), 2, (64, 4000)),
+                                (R.SYNTH_NOISE_BALL, (96, 112, 80), 1, (8, 255))):
+        with make_renderer(vra, (200, 144)) as r:
+            r.setQuirks(0); r.setLayout(R.LAYOUT_BRICKED)
+            r.generateSynthetic(synth, dims, b, 0x9E3779B9)
+            vol = r.readVolume()
+            r.setWindow(*win); r.setAlpha(0.03)
+            r.setTransferFunction(*knots)
+            tf_lut = r.getTransferLut()
+            assert np.array_equal(tf_lut[:, 0], tf_lut[:, 1]) and np.array_equal(tf_lut[:, 0], tf_lut[:, 2])     # grey: the fold applies
+            for name, block in orbit_blocks(oracle)[:3]:
+                r.setCameraBlock(block)
+                p = oracle.OracleParams(200, 144, cam=block, alpha_scale=0.03, min_val=win[0], max_val=win[1], tf_rgba=tf_lut)
+                want, _, want_spp = oracle.render(vol, p, want_spp=True)
+                seen = {}
+                for variant in (0, 2, 3, 1):                             # measured choice, fast kernel, relay kernel, generic
+                    r.setFilter(R.FILTER_NEAREST); r.setKernelVariant(variant); r.render()
+                    seen[variant] = r.last_kernel_name
+                    got = r.readPixels()
+                    _, spp = r.countSamples(per_pixel=True)
+                    assert_same(got, want, spp, want_spp, what=f"grey TF {dims} x{b} window {win} {name} variant {variant} [{r.last_kernel_name}]")
+                    if b == 2 and variant == 2:
+                        assert r.pack12Bytes() > 0                        # the packed copy (voxel - minimum) was the source of the fast kernel's gathers
+                assert seen[2] == "raymarch_fast_kernel" and seen[3] == "raymarch_relay_kernel" and seen[1] == "raymarch_generic_kernel", seen
+                # TRILINEAR through the same grey table: the staged kernel, against the oracle's filtered frame
+                r.setFilter(R.FILTER_TRILINEAR); r.setKernelVariant(0); r.render()
+                p.filter = 1
+                want_t, _, want_spp_t = oracle.render(vol, p, want_spp=True)
+                got = r.readPixels()
+                _, spp = r.countSamples(per_pixel=True)
+                assert_same(got, want_t, spp, want_spp_t, what=f"grey TF TRILINEAR {dims} x{b} {name} [{r.last_kernel_name}]")
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16], ids=["u8", "u16"])
 def test_trilinear_apron_copy_is_invisible(vra, oracle, dtype):
     """TRILINEAR on the bricked layout gathers from the apron copy (every 4^3 brick stored as 5x4x4): frames equal the

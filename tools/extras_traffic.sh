@@ -17,6 +17,17 @@ run() {   # key, bench args...
   python tools/pmc_valu.py "$OUT" "$KEY"
 }
 if [ "${1:-all}" = "one" ]; then shift; run "$@"; exit 0; fi      # tools/extras_traffic.sh one <key> <bench args...>
+modes() {   # round 6: the reference's other modes at size (MIP, the rotated views), both filters
+run mip_deep --mip
+run view_top_deep --view top
+run view_bottom_deep --view bottom
+run trilinear_mip_deep --mip --filter trilinear
+run trilinear_view_top_deep --view top --filter trilinear
+run trilinear_view_bottom_deep --view bottom --filter trilinear
+run cfg4_mip --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --mip
+run cfg4_mip_trilinear --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --mip --filter trilinear
+}
+if [ "${1:-all}" = "modes" ]; then modes; exit 0; fi
 [ "${1:-all}" = "trilinear_cfgs" ] || {
 run cfg1_shape --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255
 run cfg2_shape_ert_window --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095
@@ -38,3 +49,4 @@ run cfg1_shape_trilinear_skip --volume 256 --bytes 1 --synth sphere --width 1280
 run cfg1_shape_skip --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --skip-empty
 run cfg2_shape_ert_window_trilinear_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --filter trilinear --skip-empty
 run cfg2_shape_ert_window_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --skip-empty
+modes

@@ -51,7 +51,6 @@ RendererCore::~RendererCore()
         if (d_tile_table_tall_) (void)hipFree(d_tile_table_tall_);
         if (d_tile_table_small_) (void)hipFree(d_tile_table_small_);
         if (d_tile_work_) (void)hipFree(d_tile_work_);
-        if (d_skip_count_) (void)hipFree(d_skip_count_);
         if (d_spp_) (void)hipFree(d_spp_);
         if (d_scratch_) (void)hipFree(d_scratch_);
         if (d_rgba8_) (void)hipFree(d_rgba8_);
@@ -213,7 +212,6 @@ void RendererCore::freeVolume()
     if (d_vol_) { (void)hipFree(d_vol_); d_vol_ = nullptr; vol_alloc_bytes_ = 0; }
     res_dims_[0] = res_dims_[1] = res_dims_[2] = 0; res_bytes_ = 0;
     if (d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; skip_grid_cells_ = 0; }
-    skip_count_thresh_ = -0x7fffffff;
     if (tile_table_skip_sig_ != 0) tile_table_skip_sig_ = -1;            // (an order built on the old volume's visibility)
     if (d_vol12_) { (void)hipFree(d_vol12_); d_vol12_ = nullptr; vol12_bytes_ = 0; }
     vol12_failed_ = false;
@@ -661,7 +659,7 @@ void RendererCore::buildFrame(FrameParams &P, LaunchConfig &L)
         L.lut_noclamp = (exact_min_ >= u_.min_val && exact_max_ <= u_.max_val) ? 1 : 0;
         // a grey transfer function under NEAREST composite whose window fits the grey-ramp kernels' (c, a) table is folded
         // into that table: the launch runs on the MODE 0 instances (vr_kernels.hip: raymarch_fast_kernel, LUT build)
-        P.tf_grey = (!tf_lut_.empty() && tf_grey_ && u_.is_MIP != 1 && L.use_lut != 0 && width <= 4096) ? 1 : 0;
+        P.tf_grey = (!tf_lut_.empty() && tf_grey_ && filter == 0 && u_.is_MIP != 1 && L.use_lut != 0 && width <= 4096) ? 1 : 0;   // (NEAREST only: the fold lives in the fast / relay kernels' tables)
         auto is_pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
         L.pow2_dims = (is_pow2(nx) && is_pow2(ny) && is_pow2(nz)) ? 1 : 0;
     }
@@ -1211,30 +1209,26 @@ void RendererCore::refreshSkipGrid(FrameParams &P, LaunchConfig &L)
     if (cells * 2 >= (1ull << 32) || cnx >= (1u << 24) || (uint64_t)cny * cnz >= (1u << 24)) return;
     if (!d_skip_grid_) {
         uint16_t *tmp = nullptr;
-        check(hipMalloc(reinterpret_cast<void **>(&tmp), cells * sizeof(uint16_t)), "hipMalloc(skip grid tmp)");
+        check(hipMalloc(reinterpret_cast<void **>(&tmp), std::max<size_t>(cells * sizeof(uint16_t), 8)), "hipMalloc(skip grid tmp)");   // (also holds the one-word minimum below)
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_skip_grid_), cells * sizeof(uint16_t));
         if (e == hipSuccess)
             e = launch_build_skip_grid(d_vol_, res_bytes_, (uint32_t)nx, (uint32_t)ny, (uint32_t)nz, vol_layout_,
                                        bricksX(nx), bricksY(ny), tmp, d_skip_grid_, stream());
+        // ... and its smallest cell, into the scratch cell grid (one word), read back with the build's own synchronisation
+        unsigned gmin = 0;
+        if (e == hipSuccess) e = launch_min_cell(d_skip_grid_, (uint64_t)cells, reinterpret_cast<unsigned *>(tmp), stream());
+        if (e == hipSuccess) e = hipMemcpyAsync(&gmin, tmp, sizeof(gmin), hipMemcpyDeviceToHost, stream());
         if (e == hipSuccess) e = hipStreamSynchronize(stream());
         (void)hipFree(tmp);
         if (e != hipSuccess && d_skip_grid_) { (void)hipFree(d_skip_grid_); d_skip_grid_ = nullptr; }
         check(e, "build skip grid");
         skip_grid_cells_ = cells;
+        skip_grid_min_ = gmin;
     }
     // nothing to skip at this threshold (a window that starts at the data's floor): the launch takes the instances without
     // skipping -- theirs are the leaner loops (staged TRILINEAR 3.8 %, its tiles on global taps 20 %, the NEAREST kernels a
-    // workgroup of occupancy).  Counted once per threshold.
-    if (thresh != skip_count_thresh_) {
-        if (!d_skip_count_) check(hipMalloc(reinterpret_cast<void **>(&d_skip_count_), sizeof(unsigned long long)), "hipMalloc(skip count)");
-        check(launch_count_cells_le(d_skip_grid_, (uint64_t)cells, thresh, d_skip_count_, stream()), "count_cells_le_kernel");
-        unsigned long long n = 0;
-        check(hipMemcpyAsync(&n, d_skip_count_, sizeof(n), hipMemcpyDeviceToHost, stream()), "hipMemcpy(skip count)");
-        check(hipStreamSynchronize(stream()), "hipStreamSynchronize");
-        skip_empty_cells_ = n;
-        skip_count_thresh_ = thresh;
-    }
-    if (skip_empty_cells_ == 0) return;
+    // workgroup of occupancy).  A host comparison against the grid's smallest cell: no device work, no synchronisation per frame.
+    if (thresh < (int)skip_grid_min_) return;
     P.skip_empty = 1;
     P.skip_thresh = thresh;
     P.cnx = (int32_t)cnx; P.cny = (int32_t)cny; P.cnz = (int32_t)cnz;

@@ -189,9 +189,7 @@ private:
     uint64_t copiesBytes() const;            // optional copies resident now
     bool copyFits(uint64_t bytes) const;     // may another optional copy of `bytes` be allocated (budget / free device memory)?
     size_t skip_grid_cells_ = 0;
-    unsigned long long *d_skip_count_ = nullptr;   // scratch of the count below
-    int skip_count_thresh_ = -0x7fffffff;    // threshold the count below belongs to
-    uint64_t skip_empty_cells_ = 0;          // cells of the grid that can be skipped at that threshold (0: skipping stays off for the launch)
+    unsigned skip_grid_min_ = 0;             // smallest cell value of the grid (read back once when it is built): a threshold below it skips nothing and the launch keeps the instances without skipping
     void refreshSkipGrid(FrameParams &P, LaunchConfig &L);
     uint32_t *d_tile_table_ = nullptr;       // work-ordered block -> tile table (tile_schedule.h)
     size_t tile_table_capacity_ = 0, tile_table_blocks_ = 0;

@@ -182,22 +182,23 @@ hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t
     return hipGetLastError();
 }
 
-// how many cells of the dilated grid can be skipped at all for a threshold (host: refreshSkipGrid -- none: the launch runs the
-// instances without skipping, whose loops are a few percent leaner)
-__global__ __launch_bounds__(256) void count_cells_le_kernel(const uint16_t *__restrict__ grid, uint64_t cells, int thresh, unsigned long long *__restrict__ count)
+// the smallest value of the dilated grid: a threshold below it can skip nothing (host: refreshSkipGrid -- such a launch runs the
+// instances without skipping, whose loops are a few percent leaner).  Computed ONCE when the grid is built (round-5 advisor: the
+// per-threshold count it replaces drained the launch stream on every frame of a window / transfer-function slider drag)
+__global__ __launch_bounds__(256) void min_cell_kernel(const uint16_t *__restrict__ grid, uint64_t cells, unsigned *__restrict__ out)
 {
-    unsigned n = 0;
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (uint64_t)gridDim.x * blockDim.x) n += (int)grid[c] <= thresh ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) n += (unsigned)__shfl_xor((int)n, o);
-    if ((threadIdx.x & 63u) == 0u && n != 0u) atomicAdd(count, (unsigned long long)n);
+    unsigned m = 0xffffffffu;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (uint64_t)gridDim.x * blockDim.x) m = min(m, (unsigned)grid[c]);
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63u) == 0u) atomicMin(out, m);
 }
 
-hipError_t launch_count_cells_le(const uint16_t *grid, uint64_t cells, int thresh, unsigned long long *count, hipStream_t st)
+hipError_t launch_min_cell(const uint16_t *grid, uint64_t cells, unsigned *out, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned long long), st);
+    hipError_t e = hipMemsetAsync(out, 0xff, sizeof(unsigned), st);
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)std::min<uint64_t>((cells + 255) / 256, 2048u);
-    hipLaunchKernelGGL(count_cells_le_kernel, dim3(blocks), dim3(256), 0, st, grid, cells, thresh, count);
+    hipLaunchKernelGGL(min_cell_kernel, dim3(blocks), dim3(256), 0, st, grid, cells, out);
     return hipGetLastError();
 }
 

@@ -30,8 +30,8 @@ hipError_t launch_raymarch(const FrameParams &P, const LaunchConfig &L, const vo
 hipError_t launch_build_skip_grid(const void *vol, int bytes_per_voxel, uint32_t nx, uint32_t ny, uint32_t nz, int layout,
                                   uint32_t bnx, uint32_t bny, uint16_t *tmp, uint16_t *out, hipStream_t st);
 
-// number of cells of the dilated grid whose value is <= thresh (*count: device, 8 bytes)
-hipError_t launch_count_cells_le(const uint16_t *grid, uint64_t cells, int thresh, unsigned long long *count, hipStream_t st);
+// smallest value of the dilated grid (*out: device, 4 bytes): thresholds below it skip nothing
+hipError_t launch_min_cell(const uint16_t *grid, uint64_t cells, unsigned *out, hipStream_t st);
 
 // expected cost per tile under empty-space skipping (a scheduling estimate: visible stretch + empty_cost x empty stretch of the
 // longest of nine probe rays); work[2 * tiles_x * tiles_y] floats: per tile the cost with skipping and the cost without it (0, 0 = no
