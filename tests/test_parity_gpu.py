@@ -900,7 +900,7 @@ def run_random_trials(vra, oracle, seed, n_trials, extended=False, log=None):
             if pipe:
                 r.setKernelVariant(5)
             if tslab:
-                r.setKernelVariant((6, 8, 9, 10)[(trial // 3) % 4])      # round 4: whole layers, or a half-layer shape (16-bit volumes; 8-bit ones run as 6)
+                r.setKernelVariant((6, 8, 9, 10, 11)[(trial // 3) % 5])      # round 4: whole layers, or a half-layer shape (16-bit volumes; 8-bit ones run as 6); round 6: 16x16-pixel tiles
             if unstaged:
                 r.setKernelVariant(7)
             if batched:

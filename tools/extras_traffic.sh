@@ -28,7 +28,7 @@ run cfg4_mip --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 -
 run cfg4_mip_trilinear --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --mip --filter trilinear
 }
 if [ "${1:-all}" = "modes" ]; then modes; exit 0; fi
-[ "${1:-all}" = "trilinear_cfgs" ] || {
+part1() {
 run cfg1_shape --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255
 run cfg2_shape_ert_window --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095
 run cfg4_grey --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004
@@ -40,6 +40,7 @@ run shallow_alpha1_ert --alpha 1.0
 run trilinear_offaxis_deep --filter trilinear --pose offaxis
 run headline_offset1000 --synth noise_ball_ct
 }
+part2() {
 run cfg1_shape_trilinear --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --filter trilinear
 run cfg2_shape_ert_window_trilinear --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --filter trilinear
 run cfg4_grey_trilinear --volume 2048 --bytes 1 --width 3840 --height 2160 --window 8 255 --alpha 0.004 --filter trilinear
@@ -49,4 +50,7 @@ run cfg1_shape_trilinear_skip --volume 256 --bytes 1 --synth sphere --width 1280
 run cfg1_shape_skip --volume 256 --bytes 1 --synth sphere --width 1280 --height 720 --alpha 1.0 --window 0 255 --skip-empty
 run cfg2_shape_ert_window_trilinear_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --filter trilinear --skip-empty
 run cfg2_shape_ert_window_skip --dims 512 512 452 --bytes 2 --alpha 0.05 --window 1000 5095 --skip-empty
-modes
+}
+case "${1:-all}" in
+  part1) part1;; part2) part2;; part3) modes;; trilinear_cfgs) part2; modes;; *) part1; part2; modes;;
+esac

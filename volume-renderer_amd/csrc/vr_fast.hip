@@ -408,12 +408,67 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
             x += stx; y += sty; z += stz;
             return false;
         };
+        // Up to TAILK iterations of the shader's loop from (x, y, z), at most `limit` of them -- the same operations as TAILK calls of
+        // checked_step(), in another ORDER: first the positions (the shader's own iterated additions), bound tests and voxel
+        // addresses of all TAILK iterations, their fetches issued together, then classification and compositing in the shader's
+        // order, stopping at the first iteration whose test fails.  A fetch behind that point was speculative (a valid, clamped
+        // address inside the volume, or not issued at all when its own bound test failed) and is dropped.  Why: the literal loop
+        // pays one dependent memory round trip per iteration -- the ~5 samples between the end of the safe prefix and the box's
+        // face plus the prefix's remainder (< BATCH) are 8-12 serial round trips per ray, 4 % of a cfg3 tile's time and 15-20 % of
+        // a 256^3 tile's (round 3: profiles/r03_fast_kernel_phases.txt); batched they are two or three.  true = the loop ended.
+        // Measured (round 6, kernel ms, literal loop -> batches of 4): cfg1 shape 0.0517 -> 0.0475 (-8 %), cfg2 shape 0.1765 -> 0.1747,
+        // cfg3 0.463 -> 0.462; batches of 8 lose (cfg1 0.0544).  Not in ONE family of instances: the plain (not pipelined) 8-sample loop
+        // on the 12-bit packed copy -- a candidate of the measured choice on cfg3's shards -- ran 4-14 % SLOWER with it (N = 1 / 4
+        // shards 0.474 -> 0.493 / 0.187 -> 0.213, at fewer registers: a code-layout effect) and keeps the literal loop.
+#ifndef VR_TAIL_BATCH
+#define VR_TAIL_BATCH 4
+#endif
+        constexpr int TAILK = (PIPE || BATCH == 4 || !PK12) ? VR_TAIL_BATCH : 1;
+        auto checked_batch = [&](float &x, float &y, float &z, float stx, float sty, float stz, int limit) -> bool {
+            bool out[TAILK];
+            uint32_t tex[TAILK];
+            float px = x, py = y, pz = z;
+#pragma unroll
+            for (int u = 0; u < TAILK; u++) {
+                const float ux = div_mode<DIVTC>(px + P.half[0], P.ext[0], P.rext[0]);
+                const float uy = div_mode<DIVTC>(py + P.half[1], P.ext[1], P.rext[1]);
+                const float uzr = div_mode<DIVTC>(pz + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+                const float uz = 1.0f - uzr;
+                float tcx = ux, tcy = uy, tcz = uz;
+                if (VIEW == 1) { tcy = uzr; tcz = uy; }
+                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+                out[u] = tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || u >= limit;
+                tex[u] = 0u;
+                if (!out[u]) {
+                    const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
+                    const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
+                    const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
+                    tex[u] = VoxelFetch<VoxelT, BIG>::load(vol, rs, VoxelAddr<LAYOUT, BIG>::at(P, vi, vj, vk));
+                }
+                px += stx; py += sty; pz += stz;
+            }
+#pragma unroll
+            for (int u = 0; u < TAILK; u++) {
+                if (u >= limit) return false;                            // (the caller's budget, not the shader's: the loop goes on)
+                if (i >= P.max_steps || out[u] || da >= 0.95f) return true;
+                float c, cg = 0.0f, cb = 0.0f, a;
+                classify(tex[u] - (uint32_t)pkb, c, cg, cb, a);
+                accumulate(c, cg, cb, a);
+                x += stx; y += sty; z += stz;
+                i++;
+            }
+            return false;
+        };
         // ---- checked head: samples 0 .. head - 1
         if (head > 0) {
             float x = hqx, y = hqy, z = hqz;
-            for (int h = 0; h < head && !done; h++) {
-                if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) done = true;     // the ray ends inside its head
-                else i++;
+            if (TAILK > 1) {
+                for (int h = 0; h < head && !done; h += TAILK) done = checked_batch(x, y, z, dsx, dsy, dsz, head - h);     // (true: the ray ends inside its head)
+            } else {
+                for (int h = 0; h < head && !done; h++) {
+                    if (i >= P.max_steps || checked_step(x, y, z, dsx, dsy, dsz)) done = true;     // the ray ends inside its head
+                    else i++;
+                }
             }
         }
         // ---- safe prefix: software-pipelined, the next batch's gathers are in flight
@@ -482,8 +537,12 @@ __global__ __launch_bounds__(512, 1) void raymarch_fast_kernel(const FrameParams
         }
         // ---- checked tail: the shader's loop
         if (hit && !done) {
-            for (; i < P.max_steps; i++)
-                if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
+            if (TAILK > 1) {
+                while (!checked_batch(qx, qy, qz, tsx, tsy, tsz, TAILK)) {}
+            } else {
+                for (; i < P.max_steps; i++)
+                    if (checked_step(qx, qy, qz, tsx, tsy, tsz)) break;
+            }
         }
         fetches = (uint32_t)i;
     }

@@ -332,28 +332,52 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
         if (lane == 0) __hip_atomic_store(&rs.seq, (unsigned)(n + 1) | (last ? RELAY_STOP : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+    // Up to RELAY_TAILK iterations of the shader's loop (at most `limit`), as in the fast kernel's checked_batch(): positions, bound tests
+    // and addresses of all of them first, their fetches in flight together, classification and compositing in the shader's order up
+    // to the first failed test.  Wavefront 0 runs the head and the tail of a tile's rays while the other three wait: every memory
+    // round trip saved there is saved for the whole tile.  true = the loop ended.
+    constexpr int RELAY_TAILK = 4;
+    const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
+    auto checked_batch = [&](float &x, float &y, float &z, float stx, float sty, float stz, int limit,
+                             float &drgb, float &dg, float &db, float &da, int &i) -> bool {
+        bool out[RELAY_TAILK];
+        uint32_t tex[RELAY_TAILK];
+        float px = x, py = y, pz = z;
+#pragma unroll
+        for (int u = 0; u < RELAY_TAILK; u++) {
+            const float ux = div_mode<DIVTC>(px + P.half[0], P.ext[0], P.rext[0]);
+            const float uy = div_mode<DIVTC>(py + P.half[1], P.ext[1], P.rext[1]);
+            const float uzr = div_mode<DIVTC>(pz + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
+            const float uz = 1.0f - uzr;
+            float tcx = ux, tcy = uy, tcz = uz;
+            if (VIEW == 1) { tcy = uzr; tcz = uy; }
+            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
+            out[u] = tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || u >= limit;
+            tex[u] = 0u;
+            if (!out[u]) {
+                const int vi = min((int)(tcx * P.fdim[0]), nxm1), vj = min((int)(tcy * P.fdim[1]), nym1), vk = min((int)(tcz * P.fdim[2]), nzm1);
+                tex[u] = VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk));
+            }
+            px += stx; py += sty; pz += stz;
+        }
+#pragma unroll
+        for (int u = 0; u < RELAY_TAILK; u++) {
+            if (u >= limit) return false;
+            if (i >= P.max_steps || out[u] || da >= 0.95f) return true;
+            float c, cg = 0.0f, cb = 0.0f, a;
+            classify(tex[u] - (uint32_t)pkb, c, cg, cb, a);
+            accumulate(drgb, dg, db, da, c, cg, cb, a);
+            x += stx; y += sty; z += stz;
+            i++;
+        }
+        return false;
+    };
     {
         if (w == 0 && head > 0) {                            // samples 0 .. head - 1, literally, into state slot 0
             float drgb = 0.0f, dg = 0.0f, db = 0.0f, da = 0.0f, x = hqx, y = hqy, z = hqz;
             int i = 0;
-            for (int h = 0; h < head && i < P.max_steps; h++) {
-                const float ux = div_mode<DIVTC>(x + P.half[0], P.ext[0], P.rext[0]);
-                const float uy = div_mode<DIVTC>(y + P.half[1], P.ext[1], P.rext[1]);
-                const float uzr = div_mode<DIVTC>(z + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
-                const float uz = 1.0f - uzr;
-                float tcx = ux, tcy = uy, tcz = uz;
-                if (VIEW == 1) { tcy = uzr; tcz = uy; }
-                else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-                if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
-                const int vi = min((int)(tcx * P.fdim[0]), P.nx - 1);
-                const int vj = min((int)(tcy * P.fdim[1]), P.ny - 1);
-                const int vk = min((int)(tcz * P.fdim[2]), P.nz - 1);
-                float c, cg = 0.0f, cb = 0.0f, a;
-                classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)) - (uint32_t)pkb, c, cg, cb, a);
-                accumulate(drgb, dg, db, da, c, cg, cb, a);
-                x += dsx; y += dsy; z += dsz;
-                i++;
-            }
+            for (int h = 0; h < head; h += RELAY_TAILK)
+                if (checked_batch(x, y, z, dsx, dsy, dsz, head - h, drgb, dg, db, da, i)) break;
             rs.rgb[0][lane] = drgb; rs.a[0][lane] = da; rs.i[0][lane] = i;
             if (MODE >= 2) { rs.g[0][lane] = dg; rs.b[0][lane] = db; }
             da_seen = da;
@@ -387,24 +411,7 @@ __global__ __launch_bounds__(RELAY_THREADS) void raymarch_relay_kernel(const Fra
     if (POW2) { qx = qx / Sx; qy = qy / Sy; qz = qz / Sz; }   // exact: S is a power of two
     const float tsx = POW2 ? mx / Sx : mx, tsy = POW2 ? my / Sy : my, tsz = POW2 ? mz / Sz : mz;
     if (hit && !head_ended) {
-        const int nxm1 = P.nx - 1, nym1 = P.ny - 1, nzm1 = P.nz - 1;
-        for (; i < P.max_steps; i++) {
-            const float ux = div_mode<DIVTC>(qx + P.half[0], P.ext[0], P.rext[0]);
-            const float uy = div_mode<DIVTC>(qy + P.half[1], P.ext[1], P.rext[1]);
-            const float uzr = div_mode<DIVTC>(qz + P.half[2], P.ext[2], P.rext[2]);   // z before the flip of :185
-            const float uz = 1.0f - uzr;
-            float tcx = ux, tcy = uy, tcz = uz;
-            if (VIEW == 1) { tcy = uzr; tcz = uy; }
-            else if (VIEW == 2) { tcy = uz; tcz = 1.0f - uy; }
-            if (tcx > 1.0f || tcy > 1.0f || tcz > 1.0f || tcx < 0.0f || tcy < 0.0f || tcz < 0.0f || da >= 0.95f) break;
-            const int vi = min((int)(tcx * P.fdim[0]), nxm1);
-            const int vj = min((int)(tcy * P.fdim[1]), nym1);
-            const int vk = min((int)(tcz * P.fdim[2]), nzm1);
-            float c, cg = 0.0f, cb = 0.0f, a;
-            classify(VoxelFetch<VoxelT, false>::load(vol, rsrc, VoxelAddr<LAYOUT, false>::at(P, vi, vj, vk)) - (uint32_t)pkb, c, cg, cb, a);
-            accumulate(drgb, dg, db, da, c, cg, cb, a);
-            qx += tsx; qy += tsy; qz += tsz;
-        }
+        while (!checked_batch(qx, qy, qz, tsx, tsy, tsz, RELAY_TAILK, drgb, dg, db, da, i)) {}
     }
     if (!in_image) return;
     const size_t pix = (size_t)(P.fb_compact ? ly : py) * (size_t)P.img_w + (size_t)px;

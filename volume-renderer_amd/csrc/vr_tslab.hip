@@ -312,6 +312,9 @@ __global__ __launch_bounds__(64 * NW, (TslabCfg<VoxelT, MODE, NW, LDSKB, PERM, T
         x += stx; y += sty; z += stz;
         return false;
     };
+    // (round 6, measured and not kept: head and tail in batches of two iterations with their 16 fetches in flight together, as in the
+    // fast and relay kernels' checked_batch() -- cfg1 shape 0.1176 -> 0.1179 ms, cfg2 shape 0.3799 -> 0.3805, cfg3 1.116 -> 1.120: a tile's
+    // wavefronts wait at the phase barriers, not on these round trips)
     bool head_ended = false;
     if (head > 0) {                                                      // samples 0 .. head - 1
         float x = hqx, y = hqy, z = hqz;
