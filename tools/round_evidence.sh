@@ -34,8 +34,9 @@ cp profiles/launch_choices.bin $OUT/launch_choices.bin; cp profiles/traffic.json
 fi
 # 3) HBM traffic + VALU counts of every configuration bench.py reports under `extras` (incl. the MIP / rotated-view entries of round 6)
 if has B; then
+case "$PHASE" in *B[123]*) PARTS_NAMED=1;; *) PARTS_NAMED=0;; esac      # "B" alone (or "ABC"): all three parts
 for part in 1 2 3; do
-  if [ "$PHASE" = "B" ] || has B$part; then tools/extras_traffic.sh part$part >> $OUT/traffic.log 2>&1; cp profiles/traffic.json $OUT/traffic.json; cp profiles/valu.json $OUT/valu.json; fi
+  if [ $PARTS_NAMED = 0 ] || has B$part; then tools/extras_traffic.sh part$part >> $OUT/traffic.log 2>&1; cp profiles/traffic.json $OUT/traffic.json; cp profiles/valu.json $OUT/valu.json; fi
 done
 fi
 if has C; then

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -814,11 +815,21 @@ struct ChoiceRecord { uint64_t key; int32_t ncand, settled_value, heur, cand[8];
 static_assert(sizeof(ChoiceHeader) == 88 && sizeof(ChoiceRecord) == 56, "blob layout");
 void choiceDeviceName(int device, char (&out)[64])
 {
+    // the device MODEL as a string of attributes, not hipDeviceProp_t::name: under rocprofv3 hipGetDeviceProperties came back
+    // without a name (round 6: the profiled bench run rejected the blob the run before it had written), attribute queries do not differ
     std::memset(out, 0, sizeof(out));
     if (device < 0) return;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return; }
-    std::strncpy(out, prop.name, sizeof(out) - 1);
+    int cus = 0, clk = 0, l2 = 0, bus = 0, major = 0, minor = 0;
+    size_t mem = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    (void)hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, device);
+    (void)hipDeviceGetAttribute(&l2, hipDeviceAttributeL2CacheSize, device);
+    (void)hipDeviceGetAttribute(&bus, hipDeviceAttributeMemoryBusWidth, device);
+    (void)hipDeviceGetAttribute(&major, hipDeviceAttributeComputeCapabilityMajor, device);
+    (void)hipDeviceGetAttribute(&minor, hipDeviceAttributeComputeCapabilityMinor, device);
+    (void)hipDeviceTotalMem(&mem, device);
+    (void)hipGetLastError();
+    std::snprintf(out, sizeof(out), "cc%d.%d cu%d clk%d l2_%d bus%d mem%zuG", major, minor, cus, clk / 1000, l2 >> 10, bus, mem >> 30);
 }
 }  // namespace
 
