@@ -30,6 +30,9 @@ tools/profile.sh ${TAG}_trilinear --filter trilinear > $OUT/${TAG}_trilinear_sum
 cp gpurun_out/prof_${TAG}_trilinear/stats/*kernel_stats.csv $OUT/${TAG}_trilinear_kernel_stats.csv 2>/dev/null
 tools/pmc.sh ${TAG}_tslab_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE" -- --filter trilinear > $OUT/${TAG}_trilinear_sq.txt 2>&1
 tools/pmc.sh ${TAG}_tslab_offaxis_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE" -- --filter trilinear --pose offaxis > $OUT/${TAG}_trilinear_offaxis_sq.txt 2>&1
+# ... and what every renderer of the full bench (extras, the other BASELINE configs) settles on joins the blob: the PMC passes of phase B
+# and the bench lines of phase C then all start from settled choices
+python bench.py --extras --save-choices > $OUT/bench_cold_extras.json 2> $OUT/bench_cold_extras.err
 cp profiles/launch_choices.bin $OUT/launch_choices.bin; cp profiles/traffic.json $OUT/traffic.json; cp profiles/valu.json $OUT/valu.json
 fi
 # 3) HBM traffic + VALU counts of every configuration bench.py reports under `extras` (incl. the MIP / rotated-view entries of round 6)
@@ -40,9 +43,8 @@ for part in 1 2 3; do
 done
 fi
 if has C; then
-# 4) the bench line with every extra; what its renderers settled on joins the blob; then the line the driver will see (default flags)
-python bench.py --extras --save-choices > $OUT/bench_extras.json 2> $OUT/bench_extras.err
-cp profiles/launch_choices.bin $OUT/launch_choices.bin
+# 4) the bench line with every extra (traffic and launch choices from the phases above), then the line the driver will see (default flags)
+python bench.py --extras > $OUT/bench_extras.json 2> $OUT/bench_extras.err
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 5) one-device stand-ins for the multi-GPU launchers, and the N = 1..8 prediction
 python bench.py --native-group --gpus 4 --steps 50 > $OUT/bench_native_group4.json 2>&1

@@ -738,14 +738,16 @@ void RendererCore::launch(uint32_t *spp)
 // central ray keeps this share of its length along one volume axis: at 0.973 (a fifth of a voxel of shear per voxel) the
 // per-tile layer thickness already wins, 1.33 against 1.46 ms on cfg3; at 1.0 whole layers do, 1.17 against 1.20
 static constexpr double kTriWholeLayerAlignment = 0.985;
-// TRILINEAR: the small tile shape (16x16 pixels, four wavefronts, 40 KiB) is offered to the measured choice -- and is the first guess --
-// where a tile's brick layers are small against its ring: volumes up to 640 voxels along every axis (cfg1 shape 0.138 -> 0.118 ms, cfg2
-// shape 0.402 -> 0.381), and larger ones only while the launch leaves workgroup slots empty (fewer than two 32x16-pixel tiles per
-// slot of the chip, 256 CUs x 2).  A 1024^3 volume filling the screen loses (1.12 -> 1.22 ms; oblique 1.55 -> 2.74).
+// TRILINEAR: the small tile shape (16x16 pixels, four wavefronts, 40 KiB) is the FIRST GUESS where a tile's brick layers are small
+// against its ring -- volumes up to 640 voxels along every axis (cfg1 shape 0.138 -> 0.118 ms, cfg2 shape 0.402 -> 0.381) -- and a
+// CANDIDATE of the measured choice everywhere: on 1024^3 volumes it loses at the default pose (u16 1.12 -> 1.22 ms) and at strongly
+// oblique ones (zenith 60 / azimuth 45: 1.55 -> 2.75), but wins over most of an orbit (u8: 0.92-1.02 against 1.01-1.11 ms at five of
+// seven poses; u16 with the per-axis copies: 1.22 / 1.31 / 1.22 against 1.36 / 1.40 / 1.31; profiles/r06_trilinear_orbit.txt) -- which
+// pose does which is exactly what the measurement is for.
 static bool tri_small_tiles_offered(const FrameParams &P, const LaunchConfig &L, unsigned tile_active)
 {
-    if (L.tile_table_small == nullptr) return false;
-    return std::max(P.nx, std::max(P.ny, P.nz)) <= 640 || tile_active < 1024u;
+    (void)P; (void)tile_active;
+    return L.tile_table_small != nullptr;
 }
 
 // ---- the measured work model.  Which kernel is fastest for a launch depends on how many tiles have work, how long
