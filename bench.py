@@ -183,7 +183,8 @@ def run_native_group(args) -> int:
         if args.pose == "offaxis":
             m.cameraOrient(0.0, -(np.pi / 6) / 0.7, (np.pi / 4) / 0.7)
     g.each(configure)
-    for _ in range(max(args.clock_ramp_frames, 0) // 4 + args.warmup):
+    # (set-up: clock ramp + the members' measured launch choices settle -- exploration, 96 frames, one re-validation -- before the timed frames)
+    for _ in range(max(args.clock_ramp_frames, 0) // 4 + (220 if args.kernel_variant == 0 and args.clock_ramp_frames > 0 else 0) + args.warmup):
         g.render()
     g.kernelMsTake()
     # two frame slots (vr_group_render_async / vr_group_wait): the gather + assembly of frame i overlap the shard
@@ -256,7 +257,7 @@ def main():
             # reports, and if any failed, EVERY rank drops to gloo.
             import glob
             import tempfile
-            tag = os.path.join(tempfile.gettempdir(), f"vr_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}")
+            tag = os.path.join(tempfile.gettempdir(), f"vr_bench_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}_{os.getppid()}")      # (the launcher's pid: markers of an earlier, crashed job never match)
             ok, why = True, ""
             try:
                 fail_hook = os.environ.get("VR_BENCH_FAIL_NCCL_INIT")
@@ -453,8 +454,9 @@ def main():
     settle_frames, quiet = 0, 0
     if args.clock_ramp_frames > 0 and args.kernel_variant == 0:
         need_quiet = 100 if headline_choices_imported == 0 else 3
-        # (N > 1: every step is a collective, so every rank renders the same fixed number of frames)
-        while settle_frames < (220 if need_quiet > 3 else 6) if world > 1 else (settle_frames < 400 and quiet < need_quiet):
+        # (N > 1: every step is a collective, so every rank renders the same FIXED number of frames -- and the committed blob was
+        # measured on full frames, a rank's shard is a configuration of its own: exploration, 96 frames, the one re-validation)
+        while settle_frames < 220 if world > 1 else (settle_frames < 400 and quiet < need_quiet):
             frame = step()
             torch.cuda.synchronize(dev)
             quiet = 0 if (r.last_launch_choice >> 8) & 1 else quiet + 1
