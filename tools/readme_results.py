@@ -37,7 +37,8 @@ for label, e in LABELS:
         a, b = ex.get("view_top_deep"), ex.get("view_bottom_deep")
         if a and b:
             lines.append(f"| {label} | {a['kernel_ms']:.4g} / {b['kernel_ms']:.4g} | {a['msamples_per_s'] / 1e3:.0f} / {b['msamples_per_s'] / 1e3:.0f} | {a['mpixels_per_s']:.0f} / {b['mpixels_per_s']:.0f} | "
-                         f"{a['roofline_frac']:.3f} / {b['roofline_frac']:.3f} | — | {a['kernel'].replace('raymarch_', '').replace('_kernel', '')} |")
+                         f"{a['roofline_frac']:.3f} / {b['roofline_frac']:.3f} | " + (f"{a['traffic'] / 1e9:.2f} / {b['traffic'] / 1e9:.2f} GB" if a.get('traffic') and b.get('traffic') else "—")
+                         + f" | {a['kernel'].replace('raymarch_', '').replace('_kernel', '')} |")
         continue
     if e:
         lines.append(row("", label, e))
